@@ -1,0 +1,179 @@
+/*
+ * wdiff_hip.h - C ABI of libwdiff_hip.so: the MI355X (gfx950) kernels behind the WordDiffusion UNet
+ * denoising hot path.
+ *
+ * The reference (aniketntnu/WordDiffusion) is pure Python on stock PyTorch and has no FFI of its own
+ * (SURVEY.md fact 0.1, section 8b); the boundary a maintainer binds is the Python class surface
+ * (worddiffusion_amd.UNetModel / UNetModelPhosc / Diffusion / EMA).  This C ABI is what that Python
+ * surface calls (ctypes).  Every entry point:
+ *   - takes raw DEVICE pointers, sizes and a hipStream_t (passed as void*); no torch types;
+ *   - allocates nothing and takes no ownership; workspaces are passed in;
+ *   - returns 0 on success, a negative WD_E* code on a bad argument or a failed launch;
+ *   - is asynchronous on the given stream and safe to capture into a hipGraph.
+ *
+ * Data layout: feature maps are token-major ("NHWC"): row m = b*HW + y*W + x, C contiguous floats.
+ * GEMM operands are "split-bf16 planes": two bf16 matrices hi = bf16(x), lo = bf16(x - hi), consumed
+ * by v_mfma_f32_32x32x16_bf16 as hi*hi + hi*lo + lo*hi (npass = 3, ~2^-17 relative operand error,
+ * fp32 accumulate) or hi*hi only (npass = 1, plain bf16).
+ *
+ * For each function the reference code it replaces is cited as file:line of /root/reference.
+ */
+#ifndef WDIFF_HIP_H
+#define WDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WD_OK 0
+#define WD_EINVAL (-1)  /* bad argument (null pointer, unsupported size) */
+#define WD_ELAUNCH (-2) /* hip launch / runtime error */
+#define WD_ESTATE (-3)  /* call order error (e.g. graph end without begin) */
+
+#define WD_ACT_NONE 0
+#define WD_ACT_SILU 1
+#define WD_ACT_GEGLU 2 /* out[:, j] = x_j * gelu_erf(gate_j); weight rows interleaved in blocks of 32 */
+
+typedef uint16_t wd_bf16;
+
+/* One A-operand source of the tap-gather GEMM.  K contribution = ntaps * c.
+ * Row m of the output (sample b = m / hw_out, position p = m % hw_out) reads, for tap t,
+ * source row  b*hw_src + gather[t*hw_out + p]  (all-zero row when that entry is < 0);
+ * gather == NULL means the identity (row m, ntaps must be 1). */
+typedef struct wd_src {
+    const wd_bf16* hi;
+    const wd_bf16* lo; /* may be NULL when npass == 1 */
+    const int32_t* gather;
+    int32_t ld;     /* row pitch of hi/lo in elements, multiple of 8 */
+    int32_t c;      /* channels read per tap, multiple of 32 */
+    int32_t ntaps;  /* 1 (1x1 / linear) or 9 (3x3) */
+    int32_t hw_src; /* rows per sample in the source */
+} wd_src;
+
+/* out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] + rowvec[m / hw_out, n] + resid[rr(m), n] )
+ * with A = [src0 taps | src1 taps] along k.
+ * Replaces nn.Conv2d 3x3 / stride-2 / nearest-x2+3x3 / 1x1 and nn.Linear on the path:
+ * unet.py:595,621,632 (ResBlock convs + skip), :540 (Downsample), :488-499 (Upsample), :364,375 (proj_in/out),
+ * :175-183 (attention projections), :125,145 (GEGLU feed-forward), :1201-1205 (time MLP), :611 (emb_layers). */
+typedef struct wd_gemm_args {
+    wd_src src[2];
+    int32_t nsrc;
+    int32_t npass; /* 3 = split-bf16 (fp32-class), 1 = bf16 */
+    const wd_bf16* w_hi; /* [n][ktot], k contiguous */
+    const wd_bf16* w_lo;
+    int32_t m, n, ktot;
+    int32_t hw_out;       /* rows per sample of the output (1 for per-sample vectors) */
+    const float* bias;    /* [n] or NULL */
+    const float* rowvec;  /* [m / hw_out][rowvec_ld] or NULL: additive timestep/writer (FiLM) term, unet.py:660-669 */
+    int32_t rowvec_ld;
+    const float* resid;   /* [rows][resid_ld] or NULL: residual / skip input */
+    int32_t resid_ld;
+    const int64_t* resid_rows; /* NULL: row m; else row resid_rows[m] (label_emb gather, unet.py:1581) */
+    int32_t act;
+    float* out_f32;       /* [m][out_ld] or NULL */
+    int32_t out_ld;
+    wd_bf16* out_hi;      /* split-bf16 planes of the result for the next GEMM, or NULL */
+    wd_bf16* out_lo;
+    int32_t out_pl_ld;
+    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128160, 64064) */
+} wd_gemm_args;
+
+int wd_gemm(const wd_gemm_args* args, void* stream);
+
+/* GroupNorm(32 groups) statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).
+ * x: [B*hw][ld] fp32, channels [0, c) hold groups [g0, g0 + c/cpg).  Writes per (sample, chunk, group)
+ * partial (sum, sumsq) in double into part[(b*nchunk + j)*32 + g]; nchunk = wd_gn_nchunk(hw). */
+int wd_gn_nchunk(int hw);
+int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, double* part, void* stream);
+
+/* Normalise (+ optional SiLU) and emit split-bf16 planes: out[m][c_off + ch] for ch in [0, c).
+ * Also (raw_hi != NULL) the un-normalised input as planes for a 1x1 skip convolution (unet.py:632,671). */
+int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, const double* part,
+                const float* gamma, const float* beta, float eps, int silu,
+                wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int c_off,
+                wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);
+
+/* nn.LayerNorm(c, eps) over the last dim (unet.py:314-316), one row per token -> planes. */
+int wd_layernorm(const float* x, int ld, int rows, int c, const float* gamma, const float* beta, float eps,
+                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
+
+/* fp32 -> split planes (optionally through SiLU). */
+int wd_split(const float* x, int ld, int rows, int c, int silu, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld,
+             void* stream);
+
+/* softmax(q k^T * scale) v per (sample, head): CrossAttention.forward unet.py:185-279 / unetPhosc.py:176-198
+ * and Word_Attention unet.py:823-836 (heads = 1, scale = 1).  q: [B*nq][ldq], k/v: [B*nk][ldk/ldv], head h
+ * occupies columns [h*d, (h+1)*d).  Output row = b*out_rows + out_row0 + i; fp32 and/or planes. */
+int wd_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                 int batch, int heads, int nq, int nk, int d, float scale,
+                 float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int out_rows, int out_row0,
+                 void* stream);
+
+/* timestep_embedding, unet.py:96-116: planes[b][0:half] = cos(t_b * freqs), [half:2*half] = sin(...).
+ * freqs[half] is the fp32 table exp(-ln(1e4) k / half) computed by the caller with the reference's op order. */
+int wd_timestep_embedding(const int64_t* t, int batch, const float* freqs, int half,
+                          wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
+
+/* nn.Embedding lookup + positional encoding (CharacterEncoder, unet.py:860-872; PE skipped when pe == NULL,
+ * unetPhosc.py:726-729): planes[r][:] = table[ids[r]][:] + pe[r % seq_len][:]. ids are int64 or int32. */
+int wd_embed_tokens(const void* ids, int ids_are_i64, int rows, int seq_len, const float* table, int vocab, int c,
+                    const float* pe, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
+
+/* x NCHW [B][cin][h][w] -> im2col planes [B*h*w][kpad], column tap*cin + ci (3x3, pad 1); unet.py:1251. */
+int wd_im2col3x3(const float* x, int batch, int cin, int h, int w, wd_bf16* out_hi, wd_bf16* out_lo, int kpad,
+                 void* stream);
+
+/* layout changes at the API edge: NCHW [B][c][hw] <-> token-major [B*hw][ld]. */
+int wd_nchw_to_tokens(const float* x, int batch, int c, int hw, float* out, int ld, void* stream);
+int wd_tokens_to_nchw(const float* x, int ld, int batch, int c, int hw, float* out, void* stream);
+
+/* One reverse-diffusion update, train.py:229-236, on n elements per sample (any layout):
+ *   x = ca[t] * (x - cb[t] * eps) + cs[t] * z,   z = 0 when t <= 1,
+ * evaluated with the reference's rounding order (no fma contraction), ca = 1/sqrt(alpha), cb = (1-alpha)/sqrt(1-alpha_hat),
+ * cs = sqrt(beta) tabulated by the caller.  t = *t_dev (device int32, so that a captured graph can be replayed).
+ * noise != NULL: z is read from it (parity tests); else z ~ N(0,1) from Philox4x32-10 keyed by seed with counter
+ * (element/4, t, sample_offset + sample index): a sample's noise does not depend on how the batch is sharded. */
+int wd_ddpm_step(float* x, const float* eps, int batch, int n_per_sample, const float* ca, const float* cb,
+                 const float* cs, const int32_t* t_dev, const float* noise, uint64_t seed, uint64_t sample_offset,
+                 void* stream);
+
+/* *t_dev += delta; t64[b] = *t_dev for b < batch (the int64 timesteps vector the UNet takes, train.py:222). */
+int wd_advance_timestep(int32_t* t_dev, int delta, int64_t* t64, int batch, void* stream);
+
+/* N(0,1) fill with the same Philox stream family (x_T, train.py:217; noise_images eps, train.py:193). */
+int wd_randn(float* out, int batch, int n_per_sample, uint64_t seed, uint64_t sample_offset, uint32_t stream_id,
+             void* stream);
+
+/* x_t = sqrt(ah[t_b]) * x + sqrt(1 - ah[t_b]) * eps  (Diffusion.noise_images, train.py:190-194) */
+int wd_noise_images(const float* x, const float* eps, const int64_t* t, const float* alpha_hat, int batch,
+                    int n_per_sample, float* out, void* stream);
+
+/* strided device-to-device copy (rows x width_bytes); used to materialise a channel concat (unet.py:1750) only when
+ * GroupNorm groups straddle the concat boundary. */
+int wd_copy2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes, int64_t rows,
+              void* stream);
+
+/* EMA of weights, train.py:151-159: ema = ema * beta + (1 - beta) * p over one flat fp32 buffer. */
+int wd_ema_update(float* ema, const float* p, int64_t n, double beta, void* stream);
+
+/* hipGraph capture of a launch sequence (one denoising step) on `stream`. */
+int wd_graph_begin(void* stream);
+int wd_graph_end(void* stream, void** graph_exec_out);
+int wd_graph_launch(void* graph_exec, void* stream);
+int wd_graph_destroy(void* graph_exec);
+
+/* per-kernel-class timing with hipEvents recorded on the launch stream (bench.py roofline leg).
+ * classes: 0 gemm, 1 gn_stats, 2 gn_apply, 3 layernorm, 4 attention, 5 other. */
+#define WD_NCLASS 6
+int wd_prof_enable(int on);
+int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
+
+const char* wd_version(void);
+int wd_device_info(int* cu_count, int* lds_per_block, char* name, int name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,352 @@
+"""GPU parity of each C-ABI kernel (include/wdiff_hip.h) against the CPU oracle / plain fp32-fp64 torch
+references of the same op, on seeded inputs.  Tolerances: split-bf16 (npass=3) GEMMs 2e-5 relative to the
+fp64 result (operands carry 16 mantissa bits); fp32 streaming kernels 1e-6; integer indexing and the DDPM update
+bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddpm_oracle as D  # noqa: E402
+from oracle import unet_oracle as U  # noqa: E402
+from tests._common import max_rel, rel_err  # noqa: E402
+from worddiffusion_amd import _native as N  # noqa: E402
+from worddiffusion_amd.engine import conv_gather_table, geglu_interleave  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _st():
+    return torch.cuda.current_stream(torch.device(DEV)).cuda_stream
+
+
+def planes_of(x: torch.Tensor) -> torch.Tensor:
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def unplanes(p: torch.Tensor) -> torch.Tensor:
+    return p[0].float() + p[1].float()
+
+
+def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
+             want_f32=True, want_planes=False, tile=0, n=None):
+    """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src)."""
+    lib = N.lib()
+    args = N.WdGemmArgs()
+    keep = []
+    for i, (pl, c, ntaps, gather, hw_src) in enumerate(a_list):
+        s = N.WdSrc()
+        s.hi, s.lo = pl[0].data_ptr(), pl[1].data_ptr()
+        s.gather = gather.data_ptr() if gather is not None else None
+        s.ld, s.c, s.ntaps, s.hw_src = pl.shape[2], c, ntaps, hw_src
+        args.src[i] = s
+    args.nsrc, args.npass = len(a_list), npass
+    wp = planes_of(w)
+    keep.append(wp)
+    args.w_hi, args.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
+    n = w.shape[0] if n is None else n
+    args.m, args.n, args.ktot, args.hw_out = m, n, w.shape[1], hw_out
+    args.bias = bias.data_ptr() if bias is not None else None
+    if rowvec is not None:
+        args.rowvec, args.rowvec_ld = rowvec.data_ptr(), rowvec.shape[1]
+    if resid is not None:
+        args.resid, args.resid_ld = resid.data_ptr(), resid.shape[1]
+    if resid_rows is not None:
+        args.resid_rows = resid_rows.data_ptr()
+    args.act = act
+    n_out = n // 2 if act == N.ACT_GEGLU else n
+    out = torch.full((m, n_out), float("nan"), device=DEV) if want_f32 else None
+    opl = torch.zeros((2, m, n_out), dtype=torch.bfloat16, device=DEV) if want_planes else None
+    if out is not None:
+        args.out_f32, args.out_ld = out.data_ptr(), n_out
+    if opl is not None:
+        args.out_hi, args.out_lo, args.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), n_out
+    args.tile = tile
+    N.check(lib.wd_gemm(C.byref(args), _st()), "wd_gemm")
+    torch.cuda.synchronize()
+    return out, opl
+
+
+@pytest.mark.parametrize("m,n,k,tile", [(256, 320, 320, 0), (70, 4, 64, 0), (128, 64, 32, 128064), (300, 160, 96, 128160),
+                                        (257, 320, 640, 128160), (130, 100, 64, 64064), (64, 2560, 1280, 0),
+                                        (4096, 320, 2880, 0)])
+def test_gemm_linear(m, n, k, tile):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    out, opl = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, bias=b.to(DEV), tile=tile,
+                        want_planes=True)
+    assert rel_err(out.cpu(), ref) < 2e-5
+    assert rel_err(unplanes(opl).cpu(), ref) < 2e-5
+    out1, _ = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, npass=1, bias=b.to(DEV), tile=tile)
+    assert rel_err(out1.cpu(), ref) < 1e-2
+    # exactness of the split: 3-pass result equals fp64 product of the bf16x2-rounded operands to fp32 accuracy
+    a2, w2 = unplanes(planes_of(a)).double(), unplanes(planes_of(w)).double()
+    assert rel_err(out.cpu(), a2 @ w2.t() + b.double()) < 5e-6
+
+
+@pytest.mark.parametrize("mode", ["same", "down", "up"])
+@pytest.mark.parametrize("B,C,h,w,Co", [(3, 64, 8, 32, 320), (2, 32, 4, 16, 64), (1, 96, 5, 7, 33)])
+def test_gemm_conv_gather(mode, B, C, h, w, Co):
+    g = torch.Generator().manual_seed(B * 1000 + C + h)
+    x = torch.randn(B, C, h, w, generator=g)
+    wt = torch.randn(Co, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(Co, generator=g)
+    if mode == "same":
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    elif mode == "down":
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    else:
+        ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1)
+    tab, ho, wo = conv_gather_table(h, w, mode)
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous()
+    wp = wt.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()
+    out, _ = run_gemm([(planes_of(tok.to(DEV)), C, 9, torch.from_numpy(tab).to(DEV), h * w)], wp.to(DEV),
+                      B * ho * wo, ho * wo, bias=b.to(DEV))
+    got = out.cpu().reshape(B, ho, wo, Co).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_gemm_two_sources_film_residual_and_label_rows():
+    g = torch.Generator().manual_seed(5)
+    B, hw, c1, c2, n = 3, 64, 64, 128, 160
+    m = B * hw
+    a1, a2 = torch.randn(m, c1, generator=g), torch.randn(m, c2, generator=g)
+    w = torch.randn(n, c1 + c2, generator=g) / 14
+    bias, film, res = torch.randn(n, generator=g), torch.randn(B, n + 7, generator=g), torch.randn(m, n, generator=g)
+    ref = torch.cat([a1, a2], 1).double() @ w.double().t() + bias.double() + \
+        film[:, :n].double().repeat_interleave(hw, 0) + res.double()
+    out, _ = run_gemm([(planes_of(a1.to(DEV)), c1, 1, None, 0), (planes_of(a2.to(DEV)), c2, 1, None, 0)], w.to(DEV), m,
+                      hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV))
+    assert rel_err(out.cpu(), ref) < 2e-5
+    # label_emb gather + SiLU epilogue (time_embed.2 + label_emb[y] -> SiLU), unet.py:1551,1581,610
+    table = torch.randn(11, n, generator=g)
+    y = torch.tensor([3, 0, 10], dtype=torch.int64)
+    a = torch.randn(3, c1, generator=g)
+    w2 = torch.randn(n, c1, generator=g) / 8
+    ref2 = F.silu(a.double() @ w2.double().t() + bias.double() + table[y].double())
+    out2, pl2 = run_gemm([(planes_of(a.to(DEV)), c1, 1, None, 0)], w2.to(DEV), 3, 1, bias=bias.to(DEV),
+                         resid=table.to(DEV), resid_rows=y.to(DEV), act=N.ACT_SILU, want_planes=True)
+    assert rel_err(out2.cpu(), ref2) < 2e-5 and rel_err(unplanes(pl2).cpu(), ref2) < 2e-5
+
+
+def test_gemm_geglu_epilogue():
+    g = torch.Generator().manual_seed(6)
+    m, dim, inner = 200, 64, 256
+    a = torch.randn(m, dim, generator=g)
+    w = torch.randn(2 * inner, dim, generator=g) / 8
+    b = torch.randn(2 * inner, generator=g)
+    h = a.double() @ w.double().t() + b.double()
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    out, pl = run_gemm([(planes_of(a.to(DEV)), dim, 1, None, 0)], geglu_interleave(w).to(DEV), m, 1,
+                       bias=geglu_interleave(b).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=128064)
+    assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    lib = N.lib()
+    a = N.WdGemmArgs()
+    assert lib.wd_gemm(C.byref(a), _st()) == N.WD_EINVAL
+    assert lib.wd_gemm(None, _st()) == N.WD_EINVAL
+
+
+@pytest.mark.parametrize("B,hw,cs,silu,eps", [(3, 256, (320,), 1, 1e-5), (2, 64, (320, 320), 1, 1e-5),
+                                              (2, 32, (64,), 0, 1e-6), (1, 100, (64, 32), 1, 1e-5)])
+def test_groupnorm_silu_planes(B, hw, cs, silu, eps):
+    lib = N.lib()
+    g = torch.Generator().manual_seed(hw + sum(cs))
+    xs = [torch.randn(B * hw, c, generator=g) * 2 + 0.5 for c in cs]
+    ctot = sum(cs)
+    gamma, beta = torch.randn(ctot, generator=g), torch.randn(ctot, generator=g)
+    cat = torch.cat(xs, 1).reshape(B, hw, ctot).permute(0, 2, 1)
+    ref = F.group_norm(cat.double(), 32, gamma.double(), beta.double(), eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(B * hw, ctot)
+    cpg = ctot // 32
+    if any(c % cpg for c in cs):
+        pytest.skip("straddling groups are materialised by the engine (wd_copy2d)")
+    nchunk = lib.wd_gn_nchunk(hw)
+    part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+    pl = torch.zeros(2, B * hw, ctot, dtype=torch.bfloat16, device=DEV)
+    raw = torch.zeros_like(pl)
+    xd = [x.to(DEV) for x in xs]
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    g0 = 0
+    for x, c in zip(xd, cs):
+        N.check(lib.wd_gn_stats(x.data_ptr(), c, B, hw, c, cpg, g0, part.data_ptr(), _st()), "stats")
+        g0 += c // cpg
+    g0 = off = 0
+    for x, c in zip(xd, cs):
+        N.check(lib.wd_gn_apply(x.data_ptr(), c, B, hw, c, cpg, g0, part.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps,
+                                silu, pl[0].data_ptr(), pl[1].data_ptr(), ctot, off, raw[0].data_ptr(),
+                                raw[1].data_ptr(), _st()), "apply")
+        g0 += c // cpg
+        off += c
+    torch.cuda.synchronize()
+    assert max_rel(unplanes(pl).cpu(), ref) < 3e-5
+    assert max_rel(unplanes(raw).cpu(), torch.cat(xs, 1)) < 1e-5
+
+
+def test_layernorm_and_split():
+    lib = N.lib()
+    g = torch.Generator().manual_seed(9)
+    for rows, c in ((1000, 320), (37, 64), (5, 1280)):
+        x = torch.randn(rows, c, generator=g) * 3 + 1
+        ga, be = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        ref = F.layer_norm(x.double(), (c,), ga.double(), be.double(), 1e-5)
+        pl = torch.zeros(2, rows, c, dtype=torch.bfloat16, device=DEV)
+        xd, gd, bd = x.to(DEV), ga.to(DEV), be.to(DEV)
+        N.check(lib.wd_layernorm(xd.data_ptr(), c, rows, c, gd.data_ptr(), bd.data_ptr(), 1e-5, pl[0].data_ptr(),
+                                 pl[1].data_ptr(), c, _st()), "ln")
+        torch.cuda.synchronize()
+        assert max_rel(unplanes(pl).cpu(), ref) < 3e-5
+        N.check(lib.wd_split(xd.data_ptr(), c, rows, c, 1, pl[0].data_ptr(), pl[1].data_ptr(), c, _st()), "split")
+        torch.cuda.synchronize()
+        assert max_rel(unplanes(pl).cpu(), F.silu(x.double())) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,nq,nk,d,scale", [(3, 4, 256, 10, 80, 80 ** -0.5), (2, 4, 64, 64, 16, 0.25),
+                                               (2, 1, 10, 10, 320, 1.0), (2, 4, 70, 779, 80, 80 ** -0.5),
+                                               (1, 1, 769, 769, 64, 1.0)])
+def test_attention(B, H, nq, nk, d, scale):
+    lib = N.lib()
+    g = torch.Generator().manual_seed(nq + nk + d)
+    inner = H * d
+    q = torch.randn(B * nq, inner, generator=g) * 0.5
+    kv = torch.randn(B * nk, 2 * inner + 8, generator=g) * 0.5  # k at col 0, v at col inner (a wider pitch on purpose)
+    k, v = kv[:, :inner], kv[:, inner:2 * inner]
+
+    def heads(t, n):
+        return t.reshape(B, n, H, d).permute(0, 2, 1, 3).double()
+
+    att = torch.softmax(heads(q, nq) @ heads(k, nk).transpose(-1, -2) * scale, -1)
+    ref = (att @ heads(v, nk)).permute(0, 2, 1, 3).reshape(B * nq, inner)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    out = torch.zeros(B * (nq + 3), inner, device=DEV)
+    pl = torch.zeros(2, B * (nq + 3), inner, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.wd_attention(qd.data_ptr(), inner, kvd.data_ptr(), kv.shape[1], kvd.data_ptr() + 4 * inner, kv.shape[1],
+                             B, H, nq, nk, d, scale, out.data_ptr(), pl[0].data_ptr(), pl[1].data_ptr(), inner, nq + 3,
+                             2, _st()), "attn")
+    torch.cuda.synchronize()
+    got = out.cpu().reshape(B, nq + 3, inner)[:, 2:2 + nq].reshape(B * nq, inner)
+    assert max_rel(got, ref) < 2e-5
+    gotp = unplanes(pl).cpu().reshape(B, nq + 3, inner)[:, 2:2 + nq].reshape(B * nq, inner)
+    assert max_rel(gotp, ref) < 3e-5
+
+
+def test_timestep_embedding_tokens_im2col_layout():
+    lib = N.lib()
+    t = torch.tensor([0, 1, 2, 17, 500, 998, 999], dtype=torch.int64)
+    for dim in (320, 64):
+        half = dim // 2
+        freqs = torch.exp(-np.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+        pl = torch.zeros(2, 7, dim, dtype=torch.bfloat16, device=DEV)
+        td, fd = t.to(DEV), freqs.to(DEV)
+        N.check(lib.wd_timestep_embedding(td.data_ptr(), 7, fd.data_ptr(), half, pl[0].data_ptr(), pl[1].data_ptr(),
+                                          dim, _st()), "temb")
+        torch.cuda.synchronize()
+        # |arg| up to 999 rad: device sincos vs host agree to a few 1e-7 absolute; planes add 2^-17 relative
+        assert float((unplanes(pl).cpu() - U.timestep_embedding(t, dim)).abs().max()) < 2e-5
+    # embedding + PE
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(53, 64, generator=g)
+    pe = U.positional_encoding(10, 64)
+    ids = torch.randint(0, 53, (4, 10), generator=g)
+    ref = table[ids] + pe[:10]
+    pl = torch.zeros(2, 40, 64, dtype=torch.bfloat16, device=DEV)
+    idd, tabd, ped = ids.to(DEV), table.to(DEV), pe.to(DEV)
+    N.check(lib.wd_embed_tokens(idd.data_ptr(), 1, 40, 10, tabd.data_ptr(), 53, 64, ped.data_ptr(), pl[0].data_ptr(),
+                                pl[1].data_ptr(), 64, _st()), "embed")
+    torch.cuda.synchronize()
+    assert max_rel(unplanes(pl).cpu().reshape(4, 10, 64), ref) < 1e-5
+    id32 = ids.to(torch.int32).to(DEV)
+    N.check(lib.wd_embed_tokens(id32.data_ptr(), 0, 40, 10, tabd.data_ptr(), 53, 64, None, pl[0].data_ptr(),
+                                pl[1].data_ptr(), 64, _st()), "embed32")
+    torch.cuda.synchronize()
+    assert max_rel(unplanes(pl).cpu().reshape(4, 10, 64), table[ids]) < 1e-5
+    # im2col of the 4-channel latent (unet.py:1251) == unfold
+    x = torch.randn(3, 4, 8, 32, generator=g)
+    pl = torch.zeros(2, 3 * 256, 64, dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    N.check(lib.wd_im2col3x3(xd.data_ptr(), 3, 4, 8, 32, pl[0].data_ptr(), pl[1].data_ptr(), 64, _st()), "im2col")
+    torch.cuda.synchronize()
+    unf = F.unfold(x, 3, padding=1).reshape(3, 4, 9, 256).permute(0, 3, 2, 1).reshape(3 * 256, 36)  # [tap][ci]
+    got = unplanes(pl).cpu()
+    assert max_rel(got[:, :36], unf) < 1e-5 and float(got[:, 36:].abs().max()) == 0.0
+    # layout round trip
+    tok = torch.zeros(3 * 256, 4, device=DEV)
+    back = torch.zeros_like(xd)
+    N.check(lib.wd_nchw_to_tokens(xd.data_ptr(), 3, 4, 256, tok.data_ptr(), 4, _st()), "to_tok")
+    N.check(lib.wd_tokens_to_nchw(tok.data_ptr(), 4, 3, 4, 256, back.data_ptr(), _st()), "to_nchw")
+    torch.cuda.synchronize()
+    assert torch.equal(tok.cpu(), x.permute(0, 2, 3, 1).reshape(3 * 256, 4)) and torch.equal(back.cpu(), x)
+
+
+def test_ddpm_step_bit_exact_and_noise_stream():
+    lib = N.lib()
+    T = 1000
+    beta, alpha, ah = D.schedule(T)
+    ca, cb, cs = 1 / torch.sqrt(alpha), (1 - alpha) / torch.sqrt(1 - ah), torch.sqrt(beta)
+    g = torch.Generator().manual_seed(11)
+    x, eps, z = (torch.randn(5, 4, 8, 32, generator=g) for _ in range(3))
+    cad, cbd, csd = ca.to(DEV), cb.to(DEV), cs.to(DEV)
+    for i in (999, 500, 2, 1):
+        ref = D.reverse_step(beta, alpha, ah, x, eps, i, z)
+        xd, ed, zd = x.to(DEV), eps.to(DEV), z.to(DEV)
+        t_dev = torch.tensor([i], dtype=torch.int32, device=DEV)
+        t64 = torch.zeros(5, dtype=torch.int64, device=DEV)
+        N.check(lib.wd_ddpm_step(xd.data_ptr(), ed.data_ptr(), 5, 1024, cad.data_ptr(), cbd.data_ptr(), csd.data_ptr(),
+                                 t_dev.data_ptr(), zd.data_ptr(), 0, 0, _st()), "ddpm")
+        N.check(lib.wd_advance_timestep(t_dev.data_ptr(), -1, t64.data_ptr(), 5, _st()), "adv")
+        torch.cuda.synchronize()
+        assert torch.equal(xd.cpu(), ref), i  # same fp32 op order as train.py:236
+        assert int(t_dev.item()) == i - 1 and torch.equal(t64.cpu(), torch.full((5,), i - 1, dtype=torch.int64))
+    # device Philox noise: N(0,1), reproducible, and keyed by the GLOBAL sample index (shard-invariant)
+    a = torch.zeros(64, 1024, device=DEV)
+    N.check(lib.wd_randn(a.data_ptr(), 64, 1024, 1234, 0, 0, _st()), "randn")
+    b = torch.zeros(32, 1024, device=DEV)
+    N.check(lib.wd_randn(b.data_ptr(), 32, 1024, 1234, 32, 0, _st()), "randn")
+    c = torch.zeros(64, 1024, device=DEV)
+    N.check(lib.wd_randn(c.data_ptr(), 64, 1024, 1235, 0, 0, _st()), "randn")
+    torch.cuda.synchronize()
+    assert torch.equal(a[32:], b) and not torch.equal(a, c)
+    assert abs(float(a.mean())) < 0.02 and abs(float(a.std()) - 1) < 0.02
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.15 and torch.isfinite(a).all()
+    # z drawn inside the step: x_new - deterministic part == cs[t] * z with z ~ N(0,1)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    t_dev = torch.tensor([700], dtype=torch.int32, device=DEV)
+    N.check(lib.wd_ddpm_step(xd.data_ptr(), ed.data_ptr(), 5, 1024, cad.data_ptr(), cbd.data_ptr(), csd.data_ptr(),
+                             t_dev.data_ptr(), None, 77, 0, _st()), "ddpm")
+    torch.cuda.synchronize()
+    zrec = (xd.cpu() - D.reverse_step(beta, alpha, ah, x, eps, 700, torch.zeros_like(x))) / cs[700]
+    assert abs(float(zrec.mean())) < 0.05 and abs(float(zrec.std()) - 1) < 0.05
+
+
+def test_noise_images_and_ema_exact():
+    lib = N.lib()
+    _, _, ah = D.schedule(1000)
+    g = torch.Generator().manual_seed(13)
+    x, eps = torch.randn(6, 4, 8, 32, generator=g), torch.randn(6, 4, 8, 32, generator=g)
+    t = torch.tensor([1, 5, 300, 999, 2, 640], dtype=torch.int64)
+    ref = D.noise_images(ah, x, t, eps)
+    out = torch.zeros_like(x, device=DEV)
+    xd, ed, td, ad = x.to(DEV), eps.to(DEV), t.to(DEV), ah.to(DEV)
+    N.check(lib.wd_noise_images(xd.data_ptr(), ed.data_ptr(), td.data_ptr(), ad.data_ptr(), 6, 1024, out.data_ptr(),
+                                _st()), "noise_images")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+    ema, p = torch.randn(100003, generator=g), torch.randn(100003, generator=g)
+    ref = ema * 0.995 + (1 - 0.995) * p
+    ed, pd = ema.to(DEV), p.to(DEV)
+    N.check(lib.wd_ema_update(ed.data_ptr(), pd.data_ptr(), ema.numel(), 0.995, _st()), "ema")
+    torch.cuda.synchronize()
+    assert float((ed.cpu() - ref).abs().max()) <= 1e-9 + 2 ** -24 * float(ref.abs().max())

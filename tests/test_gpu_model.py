@@ -1,0 +1,199 @@
+"""GPU parity of the whole path through the public Python surface (which calls the C-ABI):
+UNet forwards against the reference's golden outputs and the oracle, the DDPM trajectory against the reference's
+recorded-noise trajectory, and size-independent properties at the benchmark size (B=64).
+Tolerance: 1e-3 relative to the fp32 reference (BASELINE.json north_star); the split-bf16 path sits ~1e-5."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddpm_oracle as D  # noqa: E402
+from oracle import unet_oracle as U  # noqa: E402
+from tests._common import (DEEP, FULL, FWD_CASES, SMALL, golden_state_dict, load_golden, make_args, max_rel,  # noqa: E402
+                           rel_err)
+from worddiffusion_amd import EMA, Diffusion, UNetModel, UNetModelPhosc  # noqa: E402
+from worddiffusion_amd.synthetic import fill_module_, synthetic_inputs  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def build(cfg, variant, phosc_on, sd=None, seed=0):
+    args = make_args(device=DEV, phosc=1 if phosc_on else 0)
+    cls = UNetModel if variant == "base" else UNetModelPhosc
+    m = cls(args=args, **cfg)
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    else:
+        fill_module_(m, seed)
+    return m.to(DEV).eval()
+
+
+def call(m, variant, x, t, ctx, y, phosc=None):
+    with torch.no_grad():
+        if variant == "base":
+            return m(x.to(DEV), None, original_images=None, timesteps=t.to(DEV), context=ctx.to(DEV), y=y.to(DEV))
+        return m(x.to(DEV), None if phosc is None else phosc.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV),
+                 y=y.to(DEV))
+
+
+@pytest.mark.parametrize("tag", sorted(FWD_CASES))
+def test_forward_matches_reference_golden(golden_dir, tag):
+    cfg, variant, phosc_on = FWD_CASES[tag]
+    g = load_golden(golden_dir, tag)
+    m = build(cfg, variant, phosc_on, golden_state_dict(g))
+    phosc = torch.from_numpy(g["phosc"]) if "phosc" in g.files else None
+    out = call(m, variant, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]),
+               torch.from_numpy(g["y"]), phosc)
+    assert out.shape == tuple(g["out"].shape) and out.dtype == torch.float32
+    err = max_rel(out.cpu(), g["out"])
+    assert err < TOL, (tag, err)
+    # the split-bf16 path is expected far inside the tolerance
+    assert err < 1e-4, (tag, err)
+
+
+def test_forward_blocks_match_oracle_taps(golden_dir):
+    """Intermediate activations (every block output) against the oracle on the small config."""
+    g = load_golden(golden_dir, "fwd_base_small")
+    sd = golden_state_dict(g)
+    for variant in ("base", "phosc"):
+        keys = {k: v for k, v in sd.items()} if variant == "base" else \
+            {k: v for k, v in sd.items() if not k.startswith(("res.", "wrd_proj."))}
+        m = build(SMALL, variant, False, keys)
+        orc = U.UNetOracle(SMALL, keys, variant, False)
+        inp = synthetic_inputs(5, seed=77, hw=(4, 8), num_classes=SMALL["num_classes"])
+        taps = {}
+        with torch.no_grad():
+            ref = orc(inp["x"], inp["t"], inp["context"], inp["y"], None, taps)
+        out = call(m, variant, inp["x"], inp["t"], inp["context"], inp["y"])
+        assert max_rel(out.cpu(), ref) < 1e-4
+        eng = m.engine
+        P = eng.plan(5, 4, 8, 10, 0)
+        torch.cuda.synchronize()
+        # the FiLM table of all ResBlocks and the conditioning context
+        ctx = (P.ctx_pl[0].float() + P.ctx_pl[1].float()).cpu().reshape(5, 10, -1)
+        assert max_rel(ctx, taps["context"]) < 1e-4
+
+
+def test_precision_modes(golden_dir):
+    g = load_golden(golden_dir, "fwd_base_full")
+    m = build(FULL, "base", False, golden_state_dict(g))
+    args = [torch.from_numpy(g[k]) for k in ("x", "t", "context", "y")]
+    e3 = max_rel(call(m, "base", *args).cpu(), g["out"])
+    m.set_precision("bf16")
+    e1 = max_rel(call(m, "base", *args).cpu(), g["out"])
+    m.set_precision("bf16x3")
+    e3b = max_rel(call(m, "base", *args).cpu(), g["out"])
+    assert e3 < 1e-4 and e3b == e3          # deterministic, fp32-class
+    assert 1e-4 < e1 < 5e-2                   # plain bf16 is NOT inside the 1e-3 parity bar: reported separately
+
+
+def test_weights_follow_parameter_updates(golden_dir):
+    g = load_golden(golden_dir, "fwd_phosc_small_nophosc")
+    m = build(SMALL, "phosc", False, golden_state_dict(g))
+    args = [torch.from_numpy(g[k]) for k in ("x", "t", "context", "y")]
+    o1 = call(m, "phosc", *args)
+    with torch.no_grad():
+        m.out[2].weight.mul_(2.0)
+        m.out[2].bias.mul_(2.0)
+    o2 = call(m, "phosc", *args)
+    assert max_rel(o2.cpu(), 2 * o1.cpu()) < 1e-5
+    m.load_state_dict(golden_state_dict(g))
+    assert torch.equal(call(m, "phosc", *args), o1)
+
+
+def test_ddpm_trajectory_matches_reference(golden_dir):
+    g = load_golden(golden_dir, "ddpm_traj")
+    T = int(g["T"])
+    m = build(SMALL, "phosc", False, seed=int(g["seed"]))
+    args = make_args(device=DEV)
+    diff = Diffusion(noise_steps=T, img_size=(32, 64), args=args)
+    noise = torch.from_numpy(g["noise"])
+    rec = []
+    labels = torch.from_numpy(g["labels"])
+
+    class IdentityVAE:
+        def decode(self, z):
+            import types
+            return types.SimpleNamespace(sample=z)
+
+    img = diff.sampling(m, IdentityVAE(), 3, str(g["word"]), labels, args, x_T=noise[0], noise=list(noise[1:]),
+                        record=rec)
+    xs = torch.stack([r.cpu() for r in rec])
+    assert xs.shape == tuple(g["x_per_step"].shape)
+    assert max_rel(xs, g["x_per_step"]) < 1e-4
+    assert float((img - torch.from_numpy(g["image"])).abs().max()) < 1e-3
+    # the captured-graph loop gives the same bits as the eager loop
+    lat_eager = diff.sampling(m, None, 3, str(g["word"]), labels, args, x_T=noise[0], noise=list(noise[1:]),
+                              use_graph=False)
+    lat_graph = diff.sampling(m, None, 3, str(g["word"]), labels, args, x_T=noise[0], noise=list(noise[1:]),
+                              use_graph=True)
+    assert torch.equal(lat_eager, lat_graph)
+    assert diff.last_stats["graph"] and diff.last_stats["steps"] == T - 1
+    assert Diffusion.sample is Diffusion.sampling
+
+
+def test_sampling_device_noise_is_shard_invariant():
+    """Rank-sharded sampling: sample g's trajectory depends on (seed, g) only."""
+    m = build(SMALL, "phosc", False, seed=5)
+    args = make_args(device=DEV)
+    diff = Diffusion(noise_steps=12, img_size=(32, 64), args=args)
+    labels = torch.tensor([1, 2, 3, 4], dtype=torch.int64)
+    words = ["MOVE", "text", "a", "Zz"]
+    full = diff.sampling(m, None, 4, words, labels, args, seed=99)
+    lo = diff.sampling(m, None, 2, words[:2], labels[:2], args, seed=99, sample_offset=0)
+    hi = diff.sampling(m, None, 2, words[2:], labels[2:], args, seed=99, sample_offset=2)
+    assert max_rel(torch.cat([lo, hi]).cpu(), full.cpu()) < 1e-5
+    assert torch.isfinite(full).all() and float(full.std()) > 0.05
+    other = diff.sampling(m, None, 4, words, labels, args, seed=100)
+    assert not torch.equal(other, full)
+
+
+def test_noise_images_and_ema_surface():
+    args = make_args(device=DEV)
+    diff = Diffusion(noise_steps=1000, img_size=(64, 256), args=args)
+    x = torch.randn(8, 4, 8, 32, device=DEV)
+    t = diff.sample_timesteps(8).to(DEV)
+    x_t, eps = diff.noise_images(x, t, seed=3)
+    ref = D.noise_images(diff.alpha_hat.cpu(), x.cpu(), t.cpu(), eps.cpu())
+    assert torch.equal(x_t.cpu(), ref)
+    assert abs(float(eps.mean())) < 0.05 and abs(float(eps.std()) - 1) < 0.05
+    m = build(SMALL, "phosc", False, seed=1)
+    ema_model = copy.deepcopy(m).eval().requires_grad_(False)
+    fill_module_(m, 2)
+    m.to(DEV)
+    before = {k: v.clone() for k, v in ema_model.state_dict().items()}
+    ema = EMA(0.995)
+    ema.step = 2000
+    ema.step_ema(ema_model, m)
+    for (k, p), q in zip(m.named_parameters(), ema_model.parameters()):
+        ref = before[k].cpu() * 0.995 + (1 - 0.995) * p.detach().cpu()
+        assert float((q.cpu() - ref).abs().max()) <= 2 ** -23 * float(ref.abs().max()) + 1e-12, k
+    ema2 = EMA(0.995)
+    ema2.step_ema(ema_model, m)  # warm-up: plain copy (train.py:161-170)
+    assert all(torch.equal(a, b) for a, b in zip(ema_model.state_dict().values(), m.state_dict().values()))
+
+
+def test_full_size_properties_b64():
+    """BASELINE configs[1] size (B=64, base UNet, 320 channels): the oracle would need minutes, so check
+    size-independent properties: determinism, and per-sample independence (GroupNorm/LayerNorm/attention are
+    per-sample: sample b of the batch == the same sample run alone)."""
+    m = build(FULL, "base", False, seed=0)
+    inp = synthetic_inputs(64, seed=2)
+    o1 = call(m, "base", inp["x"], inp["t"], inp["context"], inp["y"])
+    o2 = call(m, "base", inp["x"], inp["t"], inp["context"], inp["y"])
+    assert torch.equal(o1, o2) and torch.isfinite(o1).all()
+    for b in (0, 17, 63):
+        ob = call(m, "base", inp["x"][b:b + 1], inp["t"][b:b + 1], inp["context"][b:b + 1], inp["y"][b:b + 1])
+        assert max_rel(ob.cpu(), o1[b:b + 1].cpu()) < 1e-5, b
+    # ... and two of them against the oracle itself
+    shapes = U.state_dict_shapes(FULL, "base")
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, 0)) for k, s in shapes}
+    orc = U.UNetOracle(FULL, sd, "base", False)
+    with torch.no_grad():
+        ref = orc(inp["x"][:2], inp["t"][:2], inp["context"][:2], inp["y"][:2])
+    assert max_rel(o1[:2].cpu(), ref) < 1e-4

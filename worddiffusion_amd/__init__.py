@@ -1,0 +1,6 @@
+"""worddiffusion_amd - MI355X-native UNet denoising hot path of WordDiffusion."""
+from .unet import UNetModel
+from .unetPhosc import UNetModelPhosc
+from .diffusion import EMA, Diffusion, label_padding
+
+__all__ = ["UNetModel", "UNetModelPhosc", "Diffusion", "EMA", "label_padding"]

@@ -1,0 +1,106 @@
+"""ctypes binding of libwdiff_hip.so (include/wdiff_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or a symbol is
+absent, importing/using it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwdiff_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wdiff_hip.h")
+
+WD_OK, WD_EINVAL, WD_ELAUNCH, WD_ESTATE = 0, -1, -2, -3
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+NCLASS = 6
+CLASS_NAMES = ("gemm", "gn_stats", "gn_apply", "layernorm", "attention", "other")
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_u64 = C.c_uint64
+
+
+class WdSrc(C.Structure):
+    _fields_ = [("hi", _vp), ("lo", _vp), ("gather", _vp), ("ld", C.c_int32), ("c", C.c_int32),
+                ("ntaps", C.c_int32), ("hw_src", C.c_int32)]
+
+
+class WdGemmArgs(C.Structure):
+    _fields_ = [("src", WdSrc * 2), ("nsrc", C.c_int32), ("npass", C.c_int32), ("w_hi", _vp), ("w_lo", _vp),
+                ("m", C.c_int32), ("n", C.c_int32), ("ktot", C.c_int32), ("hw_out", C.c_int32),
+                ("bias", _vp), ("rowvec", _vp), ("rowvec_ld", C.c_int32), ("resid", _vp), ("resid_ld", C.c_int32),
+                ("resid_rows", _vp), ("act", C.c_int32), ("out_f32", _vp), ("out_ld", C.c_int32),
+                ("out_hi", _vp), ("out_lo", _vp), ("out_pl_ld", C.c_int32), ("tile", C.c_int32)]
+
+
+_SIGS = {
+    "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
+    "wd_gn_nchunk": (_i, [_i]),
+    "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wd_gn_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "wd_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "wd_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "wd_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "wd_timestep_embedding": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "wd_embed_tokens": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "wd_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "wd_nchw_to_tokens": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "wd_tokens_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "wd_ddpm_step": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp]),
+    "wd_advance_timestep": (_i, [_vp, _i, _vp, _i, _vp]),
+    "wd_randn": (_i, [_vp, _i, _i, _u64, _u64, C.c_uint32, _vp]),
+    "wd_noise_images": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wd_copy2d": (_i, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
+    "wd_ema_update": (_i, [_vp, _vp, C.c_int64, C.c_double, _vp]),
+    "wd_graph_begin": (_i, [_vp]),
+    "wd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "wd_graph_launch": (_i, [_vp, _vp]),
+    "wd_graph_destroy": (_i, [_vp]),
+    "wd_prof_enable": (_i, [_i]),
+    "wd_prof_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "wd_version": (C.c_char_p, []),
+    "wd_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+}
+
+
+def header_symbols() -> list:
+    """Every function the public header declares (used by the CPU test that the .so exports them all)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wd_[a-z0-9_]+)\s*\(", txt)))
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises if it is absent: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} is missing: build it with `python -m worddiffusion_amd.build` "
+                          "(hipcc --offload-arch=gfx950); worddiffusion_amd has no CPU/eager fallback")
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(l, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+_ERR = {WD_EINVAL: "invalid argument", WD_ELAUNCH: "HIP launch/runtime error", WD_ESTATE: "bad call order"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != WD_OK:
+        raise NativeError(f"{what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,71 @@
+// Shared device helpers and the launch wrapper of libwdiff_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wdiff_hip.h"
+
+#define WD_CLS_GEMM 0
+#define WD_CLS_GNSTATS 1
+#define WD_CLS_GNAPPLY 2
+#define WD_CLS_LN 3
+#define WD_CLS_ATTN 4
+#define WD_CLS_OTHER 5
+
+// ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
+extern "C" int wd_prof_is_on();
+void wd_prof_begin(int cls, hipStream_t s, double flops);
+void wd_prof_end(hipStream_t s);
+
+struct WdLaunchScope {
+    hipStream_t s;
+    bool on;
+    WdLaunchScope(int cls, hipStream_t st, double flops = 0.0) : s(st), on(wd_prof_is_on() != 0) {
+        if (on) wd_prof_begin(cls, s, flops);
+    }
+    ~WdLaunchScope() {
+        if (on) wd_prof_end(s);
+    }
+};
+
+static inline int wd_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? WD_OK : WD_ELAUNCH;
+}
+
+// ---- bf16 split ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wd_f2bf_bits(float x) {  // round-to-nearest-even, finite inputs
+    uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float wd_bf_bits2f(uint32_t b) { return __uint_as_float(b << 16); }
+
+__device__ __forceinline__ void wd_split1(float x, uint32_t& hi, uint32_t& lo) {
+    hi = wd_f2bf_bits(x);
+    lo = wd_f2bf_bits(x - wd_bf_bits2f(hi));
+}
+
+// four floats -> 4 hi (8 bytes) + 4 lo (8 bytes)
+__device__ __forceinline__ void wd_split4(const float4 v, uint2& hi, uint2& lo) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    wd_split1(v.x, h0, l0);
+    wd_split1(v.y, h1, l1);
+    wd_split1(v.z, h2, l2);
+    wd_split1(v.w, h3, l3);
+    hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+
+__device__ __forceinline__ float wd_silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float wd_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wd_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

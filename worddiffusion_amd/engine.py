@@ -1,0 +1,638 @@
+"""Host side of the HIP UNet forward: weight repacking, buffer planning and the launch sequence.
+
+The reference runs ``UNetModel.forward`` (``unet.py:1499-1836``) / ``UNetModelPhosc.forward``
+(``unetPhosc.py:1068-1159``) as ~150 ATen kernels over NCHW fp32 tensors.  Here the same arithmetic is a static
+list of launches of the kernels in ``csrc/`` over token-major (NHWC) buffers:
+
+  * every convolution / linear is ``wd_gemm`` (tap-gather GEMM on MFMA, split-bf16 operands);
+  * GroupNorm(+SiLU) is ``wd_gn_stats`` + ``wd_gn_apply`` which writes the GEMM operand planes directly - the
+    channel concat of the decoder (``torch.cat([h, hs.pop()], 1)``, unet.py:1750) is never materialised, the two
+    halves are normalised into one plane buffer; the 1x1 skip projection of a ResBlock is a second K-segment of
+    its last 3x3 GEMM; nearest-x2 upsampling / stride-2 are gather tables of the same GEMM;
+  * step-invariant work (CharacterEncoder, K/V projections of every cross-attention) lives in ``cond`` ops that
+    ``Diffusion.sampling`` runs once per call, the per-step ops are captured into one hipGraph.
+
+Torch is used for device memory, the weight repack at load time and stream handles only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .layers import (DownsampleParams, ResBlockParams, SpatialTransformerParams, UpsampleParams)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def conv_gather_table(h: int, w: int, mode: str) -> Tuple[np.ndarray, int, int]:
+    """int32 [9][h_out*w_out] source position (or -1 = zero padding) per 3x3 tap.
+
+    mode 'same': 3x3 pad 1 (unet.py:595); 'down': 3x3 stride 2 pad 1 (unet.py:540-542);
+    'up': nearest x2 then 3x3 pad 1 (unet.py:497-499) - (h, w) is the INPUT size in all modes."""
+    if mode == "same":
+        ho, wo = h, w
+    elif mode == "down":
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    elif mode == "up":
+        ho, wo = 2 * h, 2 * w
+    else:
+        raise ValueError(mode)
+    yy, xx = np.meshgrid(np.arange(ho), np.arange(wo), indexing="ij")
+    tab = np.full((9, ho * wo), -1, dtype=np.int32)
+    for tap in range(9):
+        dy, dx = tap // 3 - 1, tap % 3 - 1
+        if mode == "same":
+            sy, sx = yy + dy, xx + dx
+            ok = (sy >= 0) & (sy < h) & (sx >= 0) & (sx < w)
+        elif mode == "down":
+            sy, sx = 2 * yy + dy, 2 * xx + dx
+            ok = (sy >= 0) & (sy < h) & (sx >= 0) & (sx < w)
+        else:
+            uy, ux = yy + dy, xx + dx  # coordinates in the upsampled map
+            ok = (uy >= 0) & (uy < ho) & (ux >= 0) & (ux < wo)
+            sy, sx = uy // 2, ux // 2
+        idx = sy * w + sx
+        tab[tap] = np.where(ok, idx, -1).reshape(-1)
+    return tab, ho, wo
+
+
+def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
+    """Rows [x | gate] (unet.py:128 ``chunk(2)``) -> blocks of 32 x-rows followed by their 32 gate rows, so
+    that one wave of ``wd_gemm`` holds both halves of an output column in the same lane."""
+    inner = w.shape[0] // 2
+    assert inner % 32 == 0
+    x = w[:inner].reshape(inner // 32, 32, *w.shape[1:])
+    g = w[inner:].reshape(inner // 32, 32, *w.shape[1:])
+    return torch.stack([x, g], dim=1).reshape(w.shape)
+
+
+class Act:
+    """A token-major fp32 feature map [B*h*w, c] on the device."""
+    __slots__ = ("t", "c", "h", "w")
+
+    def __init__(self, t, c, h, w):
+        self.t, self.c, self.h, self.w = t, c, h, w
+
+
+class Plan:
+    def __init__(self):
+        self.cond: List[tuple] = []
+        self.step: List[tuple] = []
+        self.keep: List[object] = []
+        self.out: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def _run(ops, stream):
+        for fn, args, what in ops:
+            rc = fn(*args, stream)
+            if rc != 0:
+                N.check(rc, what)
+
+    def run_cond(self, stream):
+        self._run(self.cond, stream)
+
+    def run_step(self, stream):
+        self._run(self.step, stream)
+
+
+def _ptr(t: Optional[torch.Tensor], byte_off: int = 0):
+    return None if t is None else t.data_ptr() + byte_off
+
+
+class UNetEngine:
+    """Builds and runs the launch plan for one model instance."""
+
+    def __init__(self, model, variant: str):
+        self.model = model
+        self.variant = variant  # 'base' | 'phosc'
+        self.lib = N.lib()
+        self.npass = 3
+        self._sig = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._plans: Dict[tuple, Plan] = {}
+        self._tabs: Dict[tuple, torch.Tensor] = {}
+        self.device = None
+
+    # ------------------------------------------------------------------------------------------ weights
+    def set_precision(self, mode: str):
+        npass = {"bf16x3": 3, "fp32": 3, "bf16": 1}[mode]
+        if npass != self.npass:
+            self.npass = npass
+            self._plans.clear()
+
+    def _signature(self):
+        ps = list(self.model.parameters())
+        return (sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), str(ps[0].device))
+
+    def _recipes(self):
+        """name -> callable producing the fp32 matrix / vector the kernels consume (reference layouts in)."""
+        m = self.model
+        rec = {}
+
+        def conv3(wt):  # [N, C, 3, 3] -> [N, 9*C] (tap-major, channel fastest)
+            return wt.permute(0, 2, 3, 1).reshape(wt.shape[0], -1)
+
+        def conv1(wt):
+            return wt.reshape(wt.shape[0], -1)
+
+        def padk(w2, kpad):
+            out = w2.new_zeros(w2.shape[0], kpad)
+            out[:, : w2.shape[1]] = w2
+            return out
+
+        film_w, film_b = [], []
+        self.film_off = {}
+        off = 0
+        cin_conv = m.input_blocks[0][0]
+        self.kpad_in = ((9 * cin_conv.in_channels + 31) // 32) * 32
+        rec["in.w"] = lambda: padk(conv3(cin_conv.weight), self.kpad_in)
+        rec["in.b"] = lambda: cin_conv.bias
+        rec["te0.w"] = lambda: m.time_embed[0].weight
+        rec["te0.b"] = lambda: m.time_embed[0].bias
+        rec["te2.w"] = lambda: m.time_embed[2].weight
+        rec["te2.b"] = lambda: m.time_embed[2].bias
+        if m.num_classes is not None:
+            rec["label"] = lambda: m.label_emb.weight
+        we = m.word_emb
+        rec["we.table"] = lambda: we.embedding.weight
+        rec["we.qkv.w"] = lambda: torch.cat([we.attention.linear_query.weight, we.attention.linear_key.weight,
+                                             we.attention.linear_value.weight], 0)
+        rec["we.qkv.b"] = lambda: torch.cat([we.attention.linear_query.bias, we.attention.linear_key.bias,
+                                             we.attention.linear_value.bias], 0)
+        kv_w = []
+        self.kv_off = {}
+        kvo = 0
+        for name, mod in self._walk():
+            if isinstance(mod, ResBlockParams):
+                rec[name + ".gn1.g"] = (lambda mod=mod: mod.in_layers[0].weight)
+                rec[name + ".gn1.b"] = (lambda mod=mod: mod.in_layers[0].bias)
+                rec[name + ".c1.w"] = (lambda mod=mod: conv3(mod.in_layers[2].weight))
+                rec[name + ".c1.b"] = (lambda mod=mod: mod.in_layers[2].bias)
+                rec[name + ".gn2.g"] = (lambda mod=mod: mod.out_layers[0].weight)
+                rec[name + ".gn2.b"] = (lambda mod=mod: mod.out_layers[0].bias)
+                if mod.cin != mod.cout:
+                    rec[name + ".c2.w"] = (lambda mod=mod: torch.cat(
+                        [conv3(mod.out_layers[3].weight), conv1(mod.skip_connection.weight)], 1))
+                    rec[name + ".c2.b"] = (lambda mod=mod: mod.out_layers[3].bias + mod.skip_connection.bias)
+                else:
+                    rec[name + ".c2.w"] = (lambda mod=mod: conv3(mod.out_layers[3].weight))
+                    rec[name + ".c2.b"] = (lambda mod=mod: mod.out_layers[3].bias)
+                film_w.append(mod.emb_layers[1])
+                self.film_off[name] = off
+                off += mod.cout
+            elif isinstance(mod, DownsampleParams):
+                rec[name + ".w"] = (lambda mod=mod: conv3(mod.op.weight))
+                rec[name + ".b"] = (lambda mod=mod: mod.op.bias)
+            elif isinstance(mod, UpsampleParams):
+                rec[name + ".w"] = (lambda mod=mod: conv3(mod.conv.weight))
+                rec[name + ".b"] = (lambda mod=mod: mod.conv.bias)
+            elif isinstance(mod, SpatialTransformerParams):
+                rec[name + ".gn.g"] = (lambda mod=mod: mod.norm.weight)
+                rec[name + ".gn.b"] = (lambda mod=mod: mod.norm.bias)
+                rec[name + ".pi.w"] = (lambda mod=mod: conv1(mod.proj_in.weight))
+                rec[name + ".pi.b"] = (lambda mod=mod: mod.proj_in.bias)
+                rec[name + ".po.w"] = (lambda mod=mod: conv1(mod.proj_out.weight))
+                rec[name + ".po.b"] = (lambda mod=mod: mod.proj_out.bias)
+                for d, tb in enumerate(mod.transformer_blocks):
+                    p = f"{name}.tb{d}"
+                    for ln in ("norm1", "norm2", "norm3"):
+                        rec[f"{p}.{ln}.g"] = (lambda tb=tb, ln=ln: getattr(tb, ln).weight)
+                        rec[f"{p}.{ln}.b"] = (lambda tb=tb, ln=ln: getattr(tb, ln).bias)
+                    if self.variant == "phosc":
+                        rec[p + ".a1.qkv.w"] = (lambda tb=tb: torch.cat(
+                            [tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], 0))
+                        cross = [("a2", tb.attn2)]
+                    else:
+                        rec[p + ".a1.q.w"] = (lambda tb=tb: tb.attn1.to_q.weight)
+                        cross = [("a1", tb.attn1), ("a2", tb.attn2)]
+                    rec[p + ".a2.q.w"] = (lambda tb=tb: tb.attn2.to_q.weight)
+                    for tag, at in cross:
+                        kv_w.append(at)
+                        self.kv_off[f"{p}.{tag}"] = kvo
+                        kvo += 2 * at.to_k.weight.shape[0]
+                    for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
+                        rec[f"{p}.{tag}.o.w"] = (lambda at=at: at.to_out[0].weight)
+                        rec[f"{p}.{tag}.o.b"] = (lambda at=at: at.to_out[0].bias)
+                    rec[p + ".ff1.w"] = (lambda tb=tb: geglu_interleave(tb.ff.net[0].proj.weight))
+                    rec[p + ".ff1.b"] = (lambda tb=tb: geglu_interleave(tb.ff.net[0].proj.bias))
+                    rec[p + ".ff2.w"] = (lambda tb=tb: tb.ff.net[2].weight)
+                    rec[p + ".ff2.b"] = (lambda tb=tb: tb.ff.net[2].bias)
+        self.film_total = off
+        self.kv_total = kvo
+        rec["film.w"] = lambda: torch.cat([l.weight for l in film_w], 0)
+        rec["film.b"] = lambda: torch.cat([l.bias for l in film_w], 0)
+        if kv_w:
+            rec["kv.w"] = lambda: torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in kv_w], 0)
+        rec["out.gn.g"] = lambda: m.out[0].weight
+        rec["out.gn.b"] = lambda: m.out[0].bias
+        rec["out.w"] = lambda: conv3(m.out[2].weight)
+        rec["out.b"] = lambda: m.out[2].bias
+        return rec
+
+    def _walk(self):
+        """(name, module) of every block layer in execution order."""
+        m = self.model
+        for i, blk in enumerate(m.input_blocks):
+            for j, mod in enumerate(blk):
+                yield f"in{i}.{j}", mod
+        for j, mod in enumerate(m.middle_block):
+            yield f"mid.{j}", mod
+        for i, blk in enumerate(m.output_blocks):
+            for j, mod in enumerate(blk):
+                yield f"out{i}.{j}", mod
+
+    _MATRIX_SUFFIX = (".w",)
+
+    def refresh_weights(self, force: bool = False):
+        sig = self._signature()
+        if not force and sig == self._sig:
+            return
+        dev = next(self.model.parameters()).device
+        if dev.type != "cuda":
+            raise N.NativeError("worddiffusion_amd runs on an MI355X only: move the model to cuda "
+                                "(there is no CPU / eager fallback)")
+        if self.device is not None and dev != self.device:
+            self._w.clear()
+            self._plans.clear()
+            self._tabs.clear()
+        self.device = dev
+        with torch.no_grad():
+            for name, fn in self._recipes().items():
+                src = fn().detach().to(device=dev, dtype=torch.float32)
+                if name.endswith(".w"):
+                    src = src.contiguous()
+                    hi = src.to(torch.bfloat16)
+                    lo = (src - hi.float()).to(torch.bfloat16)
+                    packed = torch.stack([hi, lo], 0)
+                    if name not in self._w:
+                        self._w[name] = torch.empty_like(packed)
+                    self._w[name].copy_(packed)
+                else:
+                    src = src.contiguous()
+                    if name not in self._w:
+                        self._w[name] = torch.empty_like(src)
+                    self._w[name].copy_(src)
+            if "freqs" not in self._w:
+                half = self.model.model_channels // 2
+                freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+                self._w["freqs"] = freqs.to(dev)
+                self._w["pe"] = self.model.word_emb.positional_encoding.to(dev).contiguous()
+        self._sig = sig
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _table(self, h, w, mode):
+        key = (h, w, mode)
+        if key not in self._tabs:
+            tab, ho, wo = conv_gather_table(h, w, mode)
+            self._tabs[key] = (torch.from_numpy(tab).to(self.device), ho, wo)
+        return self._tabs[key]
+
+    def _f32(self, P: Plan, *shape):
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        P.keep.append(t)
+        return t
+
+    def _planes(self, P: Plan, rows, ld):
+        t = torch.zeros((2, rows, ld), dtype=torch.bfloat16, device=self.device)
+        P.keep.append(t)
+        return t
+
+    def _src(self, planes: torch.Tensor, c: int, ntaps: int = 1, gather: Optional[torch.Tensor] = None,
+             hw_src: int = 0, col_off: int = 0) -> N.WdSrc:
+        s = N.WdSrc()
+        ld = planes.shape[2]
+        s.hi = planes[0].data_ptr() + 2 * col_off
+        s.lo = planes[1].data_ptr() + 2 * col_off
+        s.gather = _ptr(gather)
+        s.ld, s.c, s.ntaps, s.hw_src = ld, c, ntaps, hw_src
+        return s
+
+    def _gemm(self, ops, what, srcs, wname, m, hw_out, bias=None, rowvec=None, rowvec_ld=0, resid=None,
+              resid_ld=0, resid_rows=None, act=N.ACT_NONE, out_f32=None, out_ld=0, out_pl=None, n=None, tile=0,
+              w_row_off=0):
+        a = N.WdGemmArgs()
+        for i, s in enumerate(srcs):
+            a.src[i] = s
+        a.nsrc = len(srcs)
+        a.npass = self.npass
+        wp = self._w[wname]
+        ktot = wp.shape[2]
+        assert ktot == sum(s.ntaps * s.c for s in srcs), (what, ktot, [(s.ntaps, s.c) for s in srcs])
+        a.w_hi = wp[0].data_ptr() + 2 * w_row_off * ktot
+        a.w_lo = wp[1].data_ptr() + 2 * w_row_off * ktot
+        a.m, a.n, a.ktot, a.hw_out = m, (wp.shape[1] if n is None else n), ktot, hw_out
+        a.bias = _ptr(bias)
+        a.rowvec, a.rowvec_ld = rowvec, rowvec_ld
+        a.resid, a.resid_ld, a.resid_rows = resid, resid_ld, resid_rows
+        a.act = act
+        a.out_f32, a.out_ld = _ptr(out_f32), out_ld
+        if out_pl is not None:
+            a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), out_pl[1].data_ptr(), out_pl.shape[2]
+        a.tile = tile
+        self._cur_plan.keep.append(a)
+        ops.append((self.lib.wd_gemm, (C.byref(a),), what))
+        return a
+
+    def _gn(self, P, ops, what, srcs: List[Act], gname, eps, silu, want_raw=False):
+        """GroupNorm over the channel concat of ``srcs`` -> planes [M, sum c] (+ raw planes)."""
+        B = self._B
+        h, w = srcs[0].h, srcs[0].w
+        hw = h * w
+        ctot = sum(s.c for s in srcs)
+        cpg = ctot // 32
+        if any(s.c % cpg for s in srcs):
+            # groups straddle the concat boundary: materialise the concat (never the case at 320+320 channels)
+            cat = self._f32(P, B * hw, ctot)
+            coff = 0
+            for s in srcs:
+                ops.append((self.lib.wd_copy2d, (cat.data_ptr() + 4 * coff, 4 * ctot, s.t.data_ptr(), 4 * s.c, 4 * s.c,
+                                                 B * hw), what + ":concat"))
+                coff += s.c
+            srcs = [Act(cat, ctot, h, w)]
+        nchunk = self.lib.wd_gn_nchunk(hw)
+        part = torch.empty((B, nchunk, 32, 2), dtype=torch.float64, device=self.device)
+        P.keep.append(part)
+        pl = self._planes(P, B * hw, ctot)
+        raw = self._planes(P, B * hw, ctot) if want_raw else None
+        g0 = 0
+        for s in srcs:
+            ops.append((self.lib.wd_gn_stats, (s.t.data_ptr(), s.c, B, hw, s.c, cpg, g0, part.data_ptr()),
+                        what + ":stats"))
+            g0 += s.c // cpg
+        g0 = coff = 0
+        gam, bet = self._w[gname + ".g"], self._w[gname + ".b"]
+        for s in srcs:
+            ops.append((self.lib.wd_gn_apply,
+                        (s.t.data_ptr(), s.c, B, hw, s.c, cpg, g0, part.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                         eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None, ctot, coff,
+                         raw[0].data_ptr() if raw is not None else None,
+                         raw[1].data_ptr() if (raw is not None and self.npass == 3) else None), what + ":apply"))
+            g0 += s.c // cpg
+            coff += s.c
+        return pl, raw
+
+    def _ln(self, P, ops, what, x: torch.Tensor, rows, c, name):
+        pl = self._planes(P, rows, c)
+        ops.append((self.lib.wd_layernorm,
+                    (x.data_ptr(), c, rows, c, self._w[name + ".g"].data_ptr(), self._w[name + ".b"].data_ptr(), 1e-5,
+                     pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None, c), what))
+        return pl
+
+    # ------------------------------------------------------------------------------------------ blocks
+    def _resblock(self, P, name, mod: ResBlockParams, srcs: List[Act]) -> Act:
+        ops = P.step
+        B = self._B
+        h, w = srcs[0].h, srcs[0].w
+        hw, M = h * w, B * h * w
+        cin, cout = mod.cin, mod.cout
+        assert cin == sum(s.c for s in srcs)
+        tab, _, _ = self._table(h, w, "same")
+        need_raw = cin != cout
+        a1, raw = self._gn(P, ops, name + ".gn1", srcs, name + ".gn1", 1e-5, True, want_raw=need_raw)
+        h1 = self._f32(P, M, cout)
+        self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
+                   bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
+                   rowvec_ld=self.film_total, out_f32=h1, out_ld=cout)
+        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w)], name + ".gn2", 1e-5, True)
+        out = self._f32(P, M, cout)
+        if need_raw:
+            self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
+                       name + ".c2.w", M, hw, bias=self._w[name + ".c2.b"], out_f32=out, out_ld=cout)
+        else:
+            self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
+                       bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=out,
+                       out_ld=cout)
+        return Act(out, cout, h, w)
+
+    def _resample(self, P, name, mod, x: Act, mode: str) -> Act:
+        ops = P.step
+        B = self._B
+        tab, ho, wo = self._table(x.h, x.w, mode)
+        pl = self._planes(P, B * x.h * x.w, x.c)
+        ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, B * x.h * x.w, x.c, 0, pl[0].data_ptr(),
+                                        pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
+        out = self._f32(P, B * ho * wo, mod.cout)
+        self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
+                   bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout)
+        return Act(out, mod.cout, ho, wo)
+
+    def _attention(self, ops, what, q, ldq, k, ldk, v, ldv, heads, nq, nk, d, scale, out_pl, out_f32=None,
+                   out_rows=None, out_row0=0):
+        B = self._B
+        ops.append((self.lib.wd_attention,
+                    (q, ldq, k, ldk, v, ldv, B, heads, nq, nk, d, float(scale), _ptr(out_f32),
+                     out_pl[0].data_ptr() if out_pl is not None else None,
+                     out_pl[1].data_ptr() if (out_pl is not None and self.npass == 3) else None,
+                     out_pl.shape[2] if out_pl is not None else out_f32.shape[-1],
+                     nq if out_rows is None else out_rows, out_row0), what))
+
+    def _transformer(self, P, name, mod: SpatialTransformerParams, x: Act) -> Act:
+        ops = P.step
+        B = self._B
+        h, w, c = x.h, x.w, x.c
+        hw, M = h * w, B * h * w
+        heads, d = mod.heads, mod.d_head
+        inner = heads * d
+        L = self._ctx_len
+        g, _ = self._gn(P, ops, name + ".gn", [x], name + ".gn", 1e-6, False)
+        tok = self._f32(P, M, inner)
+        self._gemm(ops, name + ".proj_in", [self._src(g, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
+                   out_f32=tok, out_ld=inner)
+        xpl = None
+        for di, tb in enumerate(mod.transformer_blocks):
+            p = f"{name}.tb{di}"
+            scale = d ** -0.5
+            # ---- attn1
+            if self.variant == "phosc":
+                n1 = self._ln(P, ops, p + ".norm1", tok, M, inner, p + ".norm1")
+                qkv = self._f32(P, M, 3 * inner)
+                self._gemm(ops, p + ".a1.qkv", [self._src(n1, inner)], p + ".a1.qkv.w", M, hw, out_f32=qkv,
+                           out_ld=3 * inner)
+                o1 = self._planes(P, M, inner)
+                self._attention(ops, p + ".a1", qkv.data_ptr(), 3 * inner, qkv.data_ptr() + 4 * inner, 3 * inner,
+                                qkv.data_ptr() + 8 * inner, 3 * inner, heads, hw, hw, d, scale, o1)
+            else:
+                n1 = self._ln(P, ops, p + ".norm2a", tok, M, inner, p + ".norm2")
+                q1 = self._f32(P, M, inner)
+                self._gemm(ops, p + ".a1.q", [self._src(n1, inner)], p + ".a1.q.w", M, hw, out_f32=q1, out_ld=inner)
+                ko = self.kv_off[p + ".a1"]
+                o1 = self._planes(P, M, inner)
+                self._attention(ops, p + ".a1", q1.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                                self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o1)
+            tok1 = self._f32(P, M, inner)
+            self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
+                       resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
+            # ---- attn2 (cross)
+            n2 = self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
+            q2 = self._f32(P, M, inner)
+            self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
+            ko = self.kv_off[p + ".a2"]
+            o2 = self._planes(P, M, inner)
+            self._attention(ops, p + ".a2", q2.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                            self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o2)
+            tok2 = self._f32(P, M, inner)
+            self._gemm(ops, p + ".a2.out", [self._src(o2, inner)], p + ".a2.o.w", M, hw, bias=self._w[p + ".a2.o.b"],
+                       resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner)
+            # ---- GEGLU feed-forward
+            n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
+            ffh = self._planes(P, M, 4 * inner)
+            self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1.w", M, hw, bias=self._w[p + ".ff1.b"],
+                       act=N.ACT_GEGLU, out_pl=ffh, tile=128064)
+            last = di == len(mod.transformer_blocks) - 1
+            tok = self._f32(P, M, inner)
+            xpl = self._planes(P, M, inner) if last else None
+            self._gemm(ops, p + ".ff2", [self._src(ffh, 4 * inner)], p + ".ff2.w", M, hw, bias=self._w[p + ".ff2.b"],
+                       resid=tok2.data_ptr(), resid_ld=inner, out_f32=None if last else tok, out_ld=inner,
+                       out_pl=xpl)
+        out = self._f32(P, M, c)
+        self._gemm(ops, name + ".proj_out", [self._src(xpl, inner)], name + ".po.w", M, hw,
+                   bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=out, out_ld=c)
+        return Act(out, c, h, w)
+
+    # ------------------------------------------------------------------------------------------ plan
+    def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int) -> Plan:
+        key = (B, H, W, ctx_len, phosc_len, self.npass)
+        if key in self._plans:
+            return self._plans[key]
+        m = self.model
+        lib = self.lib
+        if ctx_len + phosc_len == 0:
+            raise NotImplementedError("context=None: every reference script conditions on the word (unet.py:1605)")
+        P = Plan()
+        self._cur_plan = P
+        self._B = B
+        L = ctx_len + phosc_len
+        self._ctx_len = L
+        dev = self.device
+        mc = m.model_channels
+        ted = 4 * mc
+        cd = m.context_dim
+        lo_ok = self.npass == 3
+
+        # ---- persistent inputs (the caller copies into these; graph replays read them)
+        P.x_in = torch.zeros((B, m.in_channels, H, W), dtype=torch.float32, device=dev)
+        P.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        P.y_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        P.ctx_in = torch.zeros((B, max(ctx_len, 1)), dtype=torch.int64, device=dev)
+        P.phosc_in = torch.zeros((B, max(phosc_len, 1)), dtype=torch.int32, device=dev)
+
+        # ---- conditioning: CharacterEncoder (unet.py:851-874) + K/V of every cross-attention
+        cond = P.cond
+        ctx_pl = self._planes(P, B * L, cd)
+        msl = m.max_seq_len
+        for (ids, n_tok, row0, i64) in ((P.ctx_in, ctx_len, 0, 1), (P.phosc_in, phosc_len, ctx_len, 0)):
+            if n_tok == 0:
+                continue
+            use_pe = (self.variant == "base") or (n_tok <= msl)
+            if use_pe and n_tok > msl:
+                raise ValueError(f"context length {n_tok} exceeds max_seq_len {msl} (the reference fails too)")
+            e = self._planes(P, B * n_tok, cd)
+            cond.append((lib.wd_embed_tokens,
+                         (ids.data_ptr(), i64, B * n_tok, n_tok, self._w["we.table"].data_ptr(),
+                          self._w["we.table"].shape[0], cd, self._w["pe"].data_ptr() if use_pe else None,
+                          e[0].data_ptr(), e[1].data_ptr() if lo_ok else None, cd), "word_emb.embedding"))
+            qkv = self._f32(P, B * n_tok, 3 * cd)
+            self._gemm(cond, "word_emb.qkv", [self._src(e, cd)], "we.qkv.w", B * n_tok, n_tok,
+                       bias=self._w["we.qkv.b"], out_f32=qkv, out_ld=3 * cd)
+            # Word_Attention: softmax(q k^T) v without 1/sqrt(d) (unet.py:831-835)
+            self._attention(cond, "word_emb.attention", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
+                            qkv.data_ptr() + 8 * cd, 3 * cd, 1, n_tok, n_tok, cd, 1.0, ctx_pl, out_rows=L,
+                            out_row0=row0)
+        P.ctx_pl = ctx_pl
+        if self.kv_total:
+            self._kv = self._f32(P, B * L, self.kv_total)
+            self._gemm(cond, "cross.kv", [self._src(ctx_pl, cd)], "kv.w", B * L, L, out_f32=self._kv,
+                       out_ld=self.kv_total)
+
+        # ---- per-step: time/label embedding (unet.py:1550-1581) + all emb_layers at once (unet.py:609-615,660)
+        step = P.step
+        te = self._planes(P, B, mc)
+        step.append((lib.wd_timestep_embedding, (P.t_in.data_ptr(), B, self._w["freqs"].data_ptr(), mc // 2,
+                                                 te[0].data_ptr(), te[1].data_ptr() if lo_ok else None, mc),
+                     "timestep_embedding"))
+        e1 = self._planes(P, B, ted)
+        self._gemm(step, "time_embed.0", [self._src(te, mc)], "te0.w", B, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
+                   out_pl=e1)
+        e2 = self._planes(P, B, ted)  # SiLU(emb): the only form any consumer reads (emb_layers start with SiLU)
+        has_lab = m.num_classes is not None
+        self._gemm(step, "time_embed.2+label", [self._src(e1, ted)], "te2.w", B, 1, bias=self._w["te2.b"],
+                   resid=self._w["label"].data_ptr() if has_lab else None, resid_ld=ted if has_lab else 0,
+                   resid_rows=P.y_in.data_ptr() if has_lab else None, act=N.ACT_SILU, out_pl=e2)
+        self._film = self._f32(P, B, self.film_total)
+        self._gemm(step, "emb_layers(all)", [self._src(e2, ted)], "film.w", B, 1, bias=self._w["film.b"],
+                   out_f32=self._film, out_ld=self.film_total)
+
+        # ---- trunk
+        xin = self._planes(P, B * H * W, self.kpad_in)
+        step.append((lib.wd_im2col3x3, (P.x_in.data_ptr(), B, m.in_channels, H, W, xin[0].data_ptr(),
+                                        xin[1].data_ptr() if lo_ok else None, self.kpad_in), "im2col"))
+        h0 = self._f32(P, B * H * W, mc)
+        self._gemm(step, "input_blocks.0", [self._src(xin, self.kpad_in)], "in.w", B * H * W, H * W,
+                   bias=self._w["in.b"], out_f32=h0, out_ld=mc)
+        cur = Act(h0, mc, H, W)
+        hs = [cur]
+
+        def run_layers(prefix, blk, cur, extra=None):
+            for j, mod in enumerate(blk):
+                name = f"{prefix}.{j}"
+                if isinstance(mod, ResBlockParams):
+                    cur = self._resblock(P, name, mod, [cur] + ([extra] if (extra is not None and j == 0) else []))
+                elif isinstance(mod, SpatialTransformerParams):
+                    cur = self._transformer(P, name, mod, cur)
+                elif isinstance(mod, DownsampleParams):
+                    cur = self._resample(P, name, mod, cur, "down")
+                elif isinstance(mod, UpsampleParams):
+                    cur = self._resample(P, name, mod, cur, "up")
+                else:
+                    raise TypeError(type(mod))
+            return cur
+
+        for i, blk in enumerate(m.input_blocks):
+            if i == 0:
+                continue
+            cur = run_layers(f"in{i}", blk, cur)
+            hs.append(cur)
+        cur = run_layers("mid", m.middle_block, cur)
+        for i, blk in enumerate(m.output_blocks):
+            cur = run_layers(f"out{i}", blk, cur, extra=hs.pop())
+        g, _ = self._gn(P, step, "out.gn", [cur], "out.gn", 1e-5, True)
+        tab, _, _ = self._table(cur.h, cur.w, "same")
+        oc = m.out_channels
+        otok = self._f32(P, B * cur.h * cur.w, oc)
+        self._gemm(step, "out.conv", [self._src(g, cur.c, 9, tab, cur.h * cur.w)], "out.w", B * cur.h * cur.w,
+                   cur.h * cur.w, bias=self._w["out.b"], out_f32=otok, out_ld=oc)
+        P.out = torch.empty((B, oc, cur.h, cur.w), dtype=torch.float32, device=dev)
+        step.append((lib.wd_tokens_to_nchw, (otok.data_ptr(), oc, B, oc, cur.h * cur.w, P.out.data_ptr()),
+                     "tokens_to_nchw"))
+        P.out_tok = otok
+        self._plans[key] = P
+        return P
+
+    # ------------------------------------------------------------------------------------------ run
+    def load_inputs(self, P: Plan, x=None, t=None, context=None, y=None, phosc=None):
+        if x is not None:
+            P.x_in.copy_(x, non_blocking=True)
+        if t is not None:
+            P.t_in.copy_(t, non_blocking=True)
+        if y is not None:
+            P.y_in.copy_(y, non_blocking=True)
+        if context is not None:
+            P.ctx_in.copy_(context, non_blocking=True)
+        if phosc is not None:
+            P.phosc_in.copy_(phosc.to(torch.int32) if phosc.dtype != torch.int32 else phosc, non_blocking=True)
+
+    def forward(self, x, t, context, y, phosc=None):
+        self.refresh_weights()
+        B, _, H, W = x.shape
+        ctx_len = 0 if context is None else context.shape[1]
+        phosc_len = 0 if phosc is None else phosc.shape[1]
+        P = self.plan(B, H, W, ctx_len, phosc_len)
+        self.load_inputs(P, x, t, context, y, phosc)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        P.run_cond(stream)
+        P.run_step(stream)
+        return P.out.clone()
