@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the denoising hot path: images/s of 1000-step DDPM sampling (999 executed steps,
+reference train.py:221) of 64x256 word images = [4,8,32] latents, base UNet (unet.py semantics), batch 64 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one denoising step of the whole batch: UNet forward + x <- update with on-device noise + timestep
+decrement, replayed from one hipGraph with x resident in HBM.  value = N * B / (999 * ms_per_step): the images a
+full sampling() call of B images per GPU delivers per second at the measured step time (K defaults to 999 = one
+full call).  Ranks are independent (weak scaling, no collective in the timed loop): batch shards + per-sample
+Philox streams keyed by the global sample index.
+
+Prints ONE JSON line on rank 0 with the driver's fields plus
+  roofline     - the dominant kernel class (tap-gather MFMA GEMM): algorithmic FLOP / hipEvent-measured time;
+  cpu_baseline - the CPU oracle (a port: the reference itself does not travel) on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FULL = dict(image_size=(64, 256), in_channels=4, model_channels=320, out_channels=4, num_res_blocks=1,
+            attention_resolutions=(1, 1), channel_mult=(1, 1), num_heads=4, num_classes=339,
+            context_dim=320, vocab_size=53, max_seq_len=10)
+BATCH = 64
+T = 1000
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(dev, precision):
+    from worddiffusion_amd import UNetModel
+    from worddiffusion_amd.synthetic import fill_module_
+    args = types.SimpleNamespace(device=dev, interpolation=False, latent=True, phosc=0, phos=0)
+    m = fill_module_(UNetModel(args=args, **FULL), 0).to(dev).eval()
+    m.set_precision(precision)
+    return m, args
+
+
+class StepRunner:
+    """The loop body of Diffusion.sampling, set up once so that K steps can be timed."""
+
+    def __init__(self, model, args, dev, batch, seed, sample_offset):
+        from worddiffusion_amd import Diffusion
+        from worddiffusion_amd import _native as N
+        from worddiffusion_amd.synthetic import synthetic_inputs
+        self.N, self.lib = N, N.lib()
+        self.dev, self.batch, self.seed, self.off = dev, batch, seed, sample_offset
+        self.diff = Diffusion(noise_steps=T, img_size=(64, 256), args=args)
+        eng = model.engine
+        eng.refresh_weights()
+        inp = synthetic_inputs(batch, seed=2 + sample_offset)
+        self.P = P = eng.plan(batch, 8, 32, 10, 0)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ca, self.cb, self.cs = self.diff._step_tables(dev)
+        with torch.cuda.stream(self.stream):
+            st = self.stream.cuda_stream
+            N.check(self.lib.wd_randn(P.x_in.data_ptr(), batch, P.x_in[0].numel(), seed, sample_offset, 0, st), "randn")
+            eng.load_inputs(P, None, None, inp["context"].to(dev), inp["y"].to(dev), None)
+            self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.reset_t()
+            P.run_cond(st)
+        self.stream.synchronize()
+        self.graph = None
+
+    def reset_t(self):
+        self.t_dev.fill_(T - 1)
+        self.P.t_in.fill_(T - 1)
+
+    def one_step(self, st):
+        P, lib, N = self.P, self.lib, self.N
+        P.run_step(st)
+        N.check(lib.wd_ddpm_step(P.x_in.data_ptr(), P.out.data_ptr(), self.batch, P.x_in[0].numel(), self.ca.data_ptr(),
+                                 self.cb.data_ptr(), self.cs.data_ptr(), self.t_dev.data_ptr(), None, self.seed, self.off,
+                                 st), "ddpm_step")
+        N.check(lib.wd_advance_timestep(self.t_dev.data_ptr(), -1, P.t_in.data_ptr(), self.batch, st), "advance")
+
+    def capture(self):
+        st = self.stream.cuda_stream
+        with torch.cuda.stream(self.stream):
+            self.N.check(self.lib.wd_graph_begin(st), "graph_begin")
+            self.one_step(st)
+            g = C.c_void_p()
+            self.N.check(self.lib.wd_graph_end(st, C.byref(g)), "graph_end")
+        self.graph = g
+
+    def run(self, k):
+        """k graph replays; the timestep wraps back to T-1 after reaching 0 (index 0 is never used)."""
+        st = self.stream.cuda_stream
+        with torch.cuda.stream(self.stream):
+            left = int(self.t_dev.item())
+            done = 0
+            while done < k:
+                if left <= 0:
+                    self.reset_t()
+                    left = T - 1
+                n = min(left, k - done)
+                for _ in range(n):
+                    self.N.check(self.lib.wd_graph_launch(self.graph, st), "graph_launch")
+                left -= n
+                done += n
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (port of the reference forward, fp32 torch ops) on the host cores: B=64 forwards + update."""
+    from oracle import ddpm_oracle as D
+    from oracle import unet_oracle as U
+    from worddiffusion_amd.synthetic import synthetic_inputs, synthetic_tensor
+    torch.set_num_threads(threads)
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, 0)) for k, s in U.state_dict_shapes(FULL, "base")}
+    orc = U.UNetOracle(FULL, sd, "base")
+    inp = synthetic_inputs(BATCH, seed=2)
+    beta, alpha, ah = D.schedule(T)
+    x = inp["x"]
+    nfw = 6
+    with torch.no_grad():
+        orc(x, inp["t"], inp["context"], inp["y"])  # warm-up
+        t0 = time.perf_counter()
+        for i in range(nfw):
+            tt = torch.full((BATCH,), T - 1 - i, dtype=torch.int64)
+            eps = orc(x, tt, inp["context"], inp["y"])
+            x = D.reverse_step(beta, alpha, ah, x, eps, T - 1 - i, torch.randn_like(x))
+        dt = (time.perf_counter() - t0) / nfw
+    return dict(value=BATCH / (dt * (T - 1)), unit="images/s", cores=threads, kind="port",
+                sample=f"{nfw} denoising steps (oracle UNet forward fp32 + update) of the B={BATCH} batch after 1 warm-up, "
+                       f"{dt:.3f} s/step, extrapolated to {T - 1} steps", s_per_step=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=T - 1)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        torch.cuda.set_device(0)
+    dev = f"cuda:{local if world > 1 else 0}"
+    B = a.batch
+
+    model, args = build_model(dev, a.precision)
+    runner = StepRunner(model, args, dev, B, seed=1234, sample_offset=rank * B)
+    runner.capture()
+    runner.run(a.warmup)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    runner.run(a.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+    finite = bool(torch.isfinite(runner.P.x_in).all().item())
+
+    roof = None
+    prof_extra = None
+    if rank == 0 and not a.no_roofline:
+        # eager pass with a hipEvent pair around every launch on the launch stream (wd_prof_*): per-class time
+        from worddiffusion_amd import _native as N
+        lib = N.lib()
+        nprof = 3
+        with torch.cuda.stream(runner.stream):
+            st = runner.stream.cuda_stream
+            runner.reset_t()
+            runner.one_step(st)
+            torch.cuda.synchronize()
+            lib.wd_prof_enable(1)
+            for _ in range(nprof):
+                runner.one_step(st)
+            ms = (C.c_double * N.NCLASS)()
+            cnt = (C.c_int64 * N.NCLASS)()
+            fl = C.c_double()
+            lib.wd_prof_collect(ms, cnt, C.byref(fl))
+            lib.wd_prof_enable(0)
+        gemm_ms, gemm_n, gemm_flops = ms[0], cnt[0], fl.value
+        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roof = dict(bound="mfma", kernel="wd_gemm_kernel<BM,BN,NPASS> (tap-gather MFMA GEMM, all conv/linear layers)",
+                    achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+                    launches_per_step=gemm_n // nprof, avg_launch_us=1e3 * gemm_ms / max(gemm_n, 1),
+                    algorithmic_gflop_per_step=gemm_flops / nprof / 1e9,
+                    mfma_issue_factor=3 if a.precision == "bf16x3" else 1,
+                    note="achieved counts each multiply-add once; the split-bf16 path issues 3 MFMAs per product")
+        prof_extra = {N.CLASS_NAMES[i]: dict(ms_per_step=ms[i] / nprof, launches_per_step=int(cnt[i]) // nprof)
+                      for i in range(N.NCLASS)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(min(os.cpu_count() or 1, 64))
+
+    if rank == 0:
+        value = world * B * 1e3 / (ms_per_step * (T - 1))
+        line = dict(metric="denoised 64x256 word images/sec (1000-step DDPM), whole job", value=value, unit="images/s",
+                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+                    scaling="weak", vs_baseline=None,
+                    dtype="bf16x3" if a.precision == "bf16x3" else "bf16", data="synthetic",
+                    config=dict(workload="BASELINE configs[1]: batch 64 per GPU of 64x256 crops = [64,4,8,32] latents, "
+                                         "1000-step DDPM (999 executed steps), base unet.py UNetModel (320 ch, mult (1,1), "
+                                         "4 heads, 339 writers), random-init synthetic weights",
+                                batch_per_gpu=B, noise_steps=T, executed_steps_per_image=T - 1, forwards_per_step=1,
+                                precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
+                                           if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
+                                images_per_sec_per_gpu=value / world, output_finite=finite),
+                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

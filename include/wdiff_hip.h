@@ -146,9 +146,10 @@ int wd_advance_timestep(int32_t* t_dev, int delta, int64_t* t64, int batch, void
 int wd_randn(float* out, int batch, int n_per_sample, uint64_t seed, uint64_t sample_offset, uint32_t stream_id,
              void* stream);
 
-/* x_t = sqrt(ah[t_b]) * x + sqrt(1 - ah[t_b]) * eps  (Diffusion.noise_images, train.py:190-194) */
-int wd_noise_images(const float* x, const float* eps, const int64_t* t, const float* alpha_hat, int batch,
-                    int n_per_sample, float* out, void* stream);
+/* x_t = sqrt_ah[t_b] * x + sqrt_1m_ah[t_b] * eps  (Diffusion.noise_images, train.py:190-194); the two tables
+ * sqrt(alpha_hat) and sqrt(1 - alpha_hat) are tabulated by the caller (fp32, reference op order). */
+int wd_noise_images(const float* x, const float* eps, const int64_t* t, const float* sqrt_ah, const float* sqrt_1m_ah,
+                    int batch, int n_per_sample, float* out, void* stream);
 
 /* strided device-to-device copy (rows x width_bytes); used to materialise a channel concat (unet.py:1750) only when
  * GroupNorm groups straddle the concat boundary. */

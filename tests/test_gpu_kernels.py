@@ -339,9 +339,9 @@ def test_noise_images_and_ema_exact():
     t = torch.tensor([1, 5, 300, 999, 2, 640], dtype=torch.int64)
     ref = D.noise_images(ah, x, t, eps)
     out = torch.zeros_like(x, device=DEV)
-    xd, ed, td, ad = x.to(DEV), eps.to(DEV), t.to(DEV), ah.to(DEV)
-    N.check(lib.wd_noise_images(xd.data_ptr(), ed.data_ptr(), td.data_ptr(), ad.data_ptr(), 6, 1024, out.data_ptr(),
-                                _st()), "noise_images")
+    xd, ed, td, sa, sb = x.to(DEV), eps.to(DEV), t.to(DEV), torch.sqrt(ah).to(DEV), torch.sqrt(1 - ah).to(DEV)
+    N.check(lib.wd_noise_images(xd.data_ptr(), ed.data_ptr(), td.data_ptr(), sa.data_ptr(), sb.data_ptr(), 6, 1024,
+                                out.data_ptr(), _st()), "noise_images")
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref)
     ema, p = torch.randn(100003, generator=g), torch.randn(100003, generator=g)

@@ -53,7 +53,7 @@ _SIGS = {
     "wd_ddpm_step": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp]),
     "wd_advance_timestep": (_i, [_vp, _i, _vp, _i, _vp]),
     "wd_randn": (_i, [_vp, _i, _i, _u64, _u64, C.c_uint32, _vp]),
-    "wd_noise_images": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wd_noise_images": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wd_copy2d": (_i, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "wd_ema_update": (_i, [_vp, _vp, C.c_int64, C.c_double, _vp]),
     "wd_graph_begin": (_i, [_vp]),

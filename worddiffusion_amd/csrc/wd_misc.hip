@@ -4,6 +4,11 @@
 // EMA train.py:151-159.
 #include "wd_common.h"
 
+// The DDPM update, noise_images and the EMA are compared bit-for-bit with the reference's unfused fp32 torch ops:
+// no mul+add contraction anywhere in this translation unit.  (Plain operators are used on purpose: the header
+// intrinsics __fmul_rn/__fadd_rn are inline functions parsed with contraction allowed and fuse after inlining.)
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ void temb_kernel(const int64_t* __restrict__ t, int batch, const float* __restrict__ freqs, int half,
@@ -11,7 +16,7 @@ __global__ void temb_kernel(const int64_t* __restrict__ t, int batch, const floa
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * half) return;
     const int b = i / half, kx = i - b * half;
-    const float arg = __fmul_rn((float)t[b], freqs[kx]);
+    const float arg = (float)t[b] * freqs[kx];
     const float c = cosf(arg), s = sinf(arg);
     uint32_t h, l;
     wd_split1(c, h, l);
@@ -137,10 +142,10 @@ __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict_
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float4 ev = reinterpret_cast<const float4*>(eps)[i];
         float4 o;
-        o.x = __fadd_rn(__fmul_rn(a, __fsub_rn(xv.x, __fmul_rn(bb, ev.x))), __fmul_rn(s, z.x));
-        o.y = __fadd_rn(__fmul_rn(a, __fsub_rn(xv.y, __fmul_rn(bb, ev.y))), __fmul_rn(s, z.y));
-        o.z = __fadd_rn(__fmul_rn(a, __fsub_rn(xv.z, __fmul_rn(bb, ev.z))), __fmul_rn(s, z.z));
-        o.w = __fadd_rn(__fmul_rn(a, __fsub_rn(xv.w, __fmul_rn(bb, ev.w))), __fmul_rn(s, z.w));
+        o.x = a * (xv.x - bb * ev.x) + s * z.x;
+        o.y = a * (xv.y - bb * ev.y) + s * z.y;
+        o.z = a * (xv.z - bb * ev.z) + s * z.z;
+        o.w = a * (xv.w - bb * ev.w) + s * z.w;
         reinterpret_cast<float4*>(x)[i] = o;
     }
 }
@@ -149,6 +154,7 @@ __global__ void advance_kernel(int32_t* t_dev, int delta, int64_t* t64, int batc
     __shared__ int tn;
     if (threadIdx.x == 0) {
         tn = *t_dev + delta;
+        if (tn < 0) tn = 0;  // index 0 of the schedule is never used (train.py:221); never step below it
     }
     __syncthreads();
     const int v = tn;
@@ -168,21 +174,20 @@ __global__ void randn_kernel(float* __restrict__ out, int batch, int n4, uint64_
 }
 
 __global__ void noise_images_kernel(const float* __restrict__ x, const float* __restrict__ eps,
-                                    const int64_t* __restrict__ t, const float* __restrict__ ah, int batch, int n,
-                                    float* __restrict__ out) {
+                                    const int64_t* __restrict__ t, const float* __restrict__ sa_tab,
+                                    const float* __restrict__ sb_tab, int batch, int n, float* __restrict__ out) {
     const long total = (long)batch * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / n);
-        const float a = ah[t[b]];
-        const float sa = __fsqrt_rn(a), sb = __fsqrt_rn(__fsub_rn(1.0f, a));
-        out[i] = __fadd_rn(__fmul_rn(sa, x[i]), __fmul_rn(sb, eps[i]));
+        const float sa = sa_tab[t[b]], sb = sb_tab[t[b]];
+        out[i] = sa * x[i] + sb * eps[i];
     }
 }
 
 // python evaluates (1 - self.beta) in double; torch then multiplies the fp32 tensor by the fp32-rounded scalar
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n, float beta, float omb) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        ema[i] = __fadd_rn(__fmul_rn(ema[i], beta), __fmul_rn(omb, p[i]));
+        ema[i] = ema[i] * beta + omb * p[i];
 }
 
 inline int grid_for(long total, int block = 256, int cap = 2048) {
@@ -272,13 +277,13 @@ extern "C" int wd_randn(float* out, int batch, int n_per_sample, uint64_t seed, 
     return wd_check_launch();
 }
 
-extern "C" int wd_noise_images(const float* x, const float* eps, const int64_t* t, const float* alpha_hat, int batch,
-                               int n_per_sample, float* out, void* stream) {
-    if (!x || !eps || !t || !alpha_hat || !out || batch <= 0 || n_per_sample <= 0) return WD_EINVAL;
+extern "C" int wd_noise_images(const float* x, const float* eps, const int64_t* t, const float* sqrt_ah,
+                               const float* sqrt_1m_ah, int batch, int n_per_sample, float* out, void* stream) {
+    if (!x || !eps || !t || !sqrt_ah || !sqrt_1m_ah || !out || batch <= 0 || n_per_sample <= 0) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(noise_images_kernel, dim3(grid_for((long)batch * n_per_sample)), dim3(256), 0, st, x, eps, t,
-                       alpha_hat, batch, n_per_sample, out);
+                       sqrt_ah, sqrt_1m_ah, batch, n_per_sample, out);
     return wd_check_launch();
 }
 

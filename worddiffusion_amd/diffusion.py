@@ -105,11 +105,12 @@ class Diffusion:
             eps = torch.empty_like(x)
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else seed
             N.check(lib.wd_randn(eps.data_ptr(), x.shape[0], n, seed, 0, 1, st), "wd_randn")
-        ah = self.alpha_hat.to(x.device)
+        ah = self.alpha_hat.cpu()
+        sa, sb = torch.sqrt(ah).to(x.device), torch.sqrt(1 - ah).to(x.device)
         out = torch.empty_like(x)
         t = t.to(x.device).long().contiguous()
-        N.check(lib.wd_noise_images(x.data_ptr(), eps.data_ptr(), t.data_ptr(), ah.data_ptr(), x.shape[0], n,
-                                    out.data_ptr(), st), "wd_noise_images")
+        N.check(lib.wd_noise_images(x.data_ptr(), eps.data_ptr(), t.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                    x.shape[0], n, out.data_ptr(), st), "wd_noise_images")
         return out, eps
 
     def _step_tables(self, device):
