@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of wd_gemm on the shapes of the UNet (run on the GPU box; used for tuning and PMC runs).
+
+    python tools/gemm_bench.py [--shape conv8x32] [--tile 0] [--npass 3] [--iters 20]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from worddiffusion_amd import _native as N  # noqa: E402
+from worddiffusion_amd.engine import conv_gather_table  # noqa: E402
+
+DEV = "cuda:0"
+B = 64
+SHAPES = {
+    # name: (h, w, cin, cout, kind)   kind: conv3 | lin | conv3cat (640 -> 320 + skip) | geglu
+    "conv8x32": (8, 32, 320, 320, "conv3"),
+    "conv8x32cat": (8, 32, 640, 320, "conv3"),
+    "conv4x16": (4, 16, 320, 320, "conv3"),
+    "conv4x16cat": (4, 16, 640, 320, "conv3"),
+    "lin8x32": (8, 32, 320, 320, "lin"),
+    "ff1": (8, 32, 320, 2560, "geglu"),
+    "ff2": (8, 32, 1280, 320, "lin"),
+    "lin4x16": (4, 16, 320, 320, "lin"),
+    "temb": (1, 1, 1280, 1280, "lin"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="all")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--npass", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    lib = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    names = list(SHAPES) if a.shape == "all" else a.shape.split(",")
+    for name in names:
+        h, w, cin, cout, kind = SHAPES[name]
+        hw, m = h * w, B * h * w
+        ntaps = 9 if kind == "conv3" else 1
+        ktot = ntaps * cin
+        act = torch.randn(2, m, cin, device=DEV).to(torch.bfloat16)
+        wt = (torch.randn(2, cout, ktot, device=DEV) / ktot ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(cout, device=DEV)
+        tab = torch.from_numpy(conv_gather_table(h, w, "same")[0]).to(DEV) if ntaps == 9 else None
+        n_out = cout // 2 if kind == "geglu" else cout
+        out = torch.empty(m, n_out, device=DEV)
+        g = N.WdGemmArgs()
+        s = N.WdSrc()
+        s.hi, s.lo = act[0].data_ptr(), act[1].data_ptr()
+        s.gather = tab.data_ptr() if tab is not None else None
+        s.ld, s.c, s.ntaps, s.hw_src = cin, cin, ntaps, hw
+        g.src[0] = s
+        g.nsrc, g.npass = 1, a.npass
+        g.w_hi, g.w_lo = wt[0].data_ptr(), wt[1].data_ptr()
+        g.m, g.n, g.ktot, g.hw_out = m, cout, ktot, hw
+        g.bias = bias.data_ptr()
+        g.act = N.ACT_GEGLU if kind == "geglu" else 0
+        g.out_f32, g.out_ld = out.data_ptr(), n_out
+        g.tile = a.tile if kind != "geglu" or a.tile else 0
+        for _ in range(3):
+            N.check(lib.wd_gemm(C.byref(g), st), name)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            lib.wd_gemm(C.byref(g), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / a.iters
+        fl = 2.0 * m * cout * ktot
+        print(f"{name:12s} m={m:6d} n={cout:5d} k={ktot:5d} tile={a.tile:6d} npass={a.npass}: {us:8.1f} us  "
+              f"{fl / us / 1e6:7.1f} TF/s algorithmic ({a.npass * fl / us / 1e6:7.1f} MFMA)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
