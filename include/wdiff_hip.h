@@ -77,7 +77,12 @@ typedef struct wd_gemm_args {
     wd_bf16* out_hi;      /* split-bf16 planes of the result for the next GEMM, or NULL */
     wd_bf16* out_lo;
     int32_t out_pl_ld;
-    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128160, 64064) */
+    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128128, 128160, 64064) */
+    int32_t w_layout;     /* 0: w = [n][ktot].  1: "slab order" [stage][n][32], stage = (32-channel chunk, tap) of src0
+                           * (chunk-major, tap-minor) followed by the 32-channel chunks of src1: selects the kernel that
+                           * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2) */
+    int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192 */
+    int32_t dbg;          /* must be 0; nonzero values switch parts of the kernel off for timing experiments (results invalid) */
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);

@@ -15,7 +15,7 @@ from oracle import ddpm_oracle as D  # noqa: E402
 from oracle import unet_oracle as U  # noqa: E402
 from tests._common import max_rel, rel_err  # noqa: E402
 from worddiffusion_amd import _native as N  # noqa: E402
-from worddiffusion_amd.engine import conv_gather_table, geglu_interleave  # noqa: E402
+from worddiffusion_amd.engine import conv_gather_table, geglu_interleave, slab_order, slab_span  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -34,9 +34,13 @@ def unplanes(p: torch.Tensor) -> torch.Tensor:
     return p[0].float() + p[1].float()
 
 
+SLAB = [False, True]
+
+
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None):
-    """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src)."""
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False):
+    """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
+    slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
     args = N.WdGemmArgs()
     keep = []
@@ -48,6 +52,13 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
         args.src[i] = s
     args.nsrc, args.npass = len(a_list), npass
     wp = planes_of(w)
+    if slab:
+        g0 = a_list[0][3]
+        span = slab_span(g0.cpu().numpy() if g0 is not None else None, hw_out, a_list[0][4], m)
+        if span > 192 or tile == 64064:
+            pytest.skip("slab kernel not applicable (span / tile)")
+        wp = slab_order(wp, a_list[0][2], a_list[0][1], a_list[1][1] if len(a_list) > 1 else 0)
+        args.w_layout, args.slab_rows = 1, span
     keep.append(wp)
     args.w_hi, args.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
     n = w.shape[0] if n is None else n
@@ -76,17 +87,19 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
 @pytest.mark.parametrize("m,n,k,tile", [(256, 320, 320, 0), (70, 4, 64, 0), (128, 64, 32, 128064), (300, 160, 96, 128160),
                                         (257, 320, 640, 128160), (130, 100, 64, 64064), (64, 2560, 1280, 0),
                                         (4096, 320, 2880, 0)])
-def test_gemm_linear(m, n, k, tile):
+@pytest.mark.parametrize("slab", SLAB)
+def test_gemm_linear(m, n, k, tile, slab):
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g) / k ** 0.5
     b = torch.randn(n, generator=g)
     ref = a.double() @ w.double().t() + b.double()
     out, opl = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, bias=b.to(DEV), tile=tile,
-                        want_planes=True)
+                        want_planes=True, slab=slab)
     assert rel_err(out.cpu(), ref) < 2e-5
     assert rel_err(unplanes(opl).cpu(), ref) < 2e-5
-    out1, _ = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, npass=1, bias=b.to(DEV), tile=tile)
+    out1, _ = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, npass=1, bias=b.to(DEV), tile=tile,
+                       slab=slab)
     assert rel_err(out1.cpu(), ref) < 1e-2
     # exactness of the split: 3-pass result equals fp64 product of the bf16x2-rounded operands to fp32 accuracy
     a2, w2 = unplanes(planes_of(a)).double(), unplanes(planes_of(w)).double()
@@ -94,8 +107,9 @@ def test_gemm_linear(m, n, k, tile):
 
 
 @pytest.mark.parametrize("mode", ["same", "down", "up"])
-@pytest.mark.parametrize("B,C,h,w,Co", [(3, 64, 8, 32, 320), (2, 32, 4, 16, 64), (1, 96, 5, 7, 33)])
-def test_gemm_conv_gather(mode, B, C, h, w, Co):
+@pytest.mark.parametrize("B,C,h,w,Co", [(3, 64, 8, 32, 320), (2, 32, 4, 16, 64), (1, 96, 5, 7, 33), (5, 320, 8, 32, 320)])
+@pytest.mark.parametrize("slab", SLAB)
+def test_gemm_conv_gather(mode, B, C, h, w, Co, slab):
     g = torch.Generator().manual_seed(B * 1000 + C + h)
     x = torch.randn(B, C, h, w, generator=g)
     wt = torch.randn(Co, C, 3, 3, generator=g) / (9 * C) ** 0.5
@@ -110,12 +124,13 @@ def test_gemm_conv_gather(mode, B, C, h, w, Co):
     tok = x.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous()
     wp = wt.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()
     out, _ = run_gemm([(planes_of(tok.to(DEV)), C, 9, torch.from_numpy(tab).to(DEV), h * w)], wp.to(DEV),
-                      B * ho * wo, ho * wo, bias=b.to(DEV))
+                      B * ho * wo, ho * wo, bias=b.to(DEV), slab=slab)
     got = out.cpu().reshape(B, ho, wo, Co).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-5
 
 
-def test_gemm_two_sources_film_residual_and_label_rows():
+@pytest.mark.parametrize("slab", SLAB)
+def test_gemm_two_sources_film_residual_and_label_rows(slab):
     g = torch.Generator().manual_seed(5)
     B, hw, c1, c2, n = 3, 64, 64, 128, 160
     m = B * hw
@@ -125,8 +140,18 @@ def test_gemm_two_sources_film_residual_and_label_rows():
     ref = torch.cat([a1, a2], 1).double() @ w.double().t() + bias.double() + \
         film[:, :n].double().repeat_interleave(hw, 0) + res.double()
     out, _ = run_gemm([(planes_of(a1.to(DEV)), c1, 1, None, 0), (planes_of(a2.to(DEV)), c2, 1, None, 0)], w.to(DEV), m,
-                      hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV))
+                      hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV), slab=slab)
     assert rel_err(out.cpu(), ref) < 2e-5
+    # 3x3 taps on the first source + identity second source (ResBlock conv2 | 1x1 skip, unet.py:621,632,671)
+    hh, ww = 8, 8
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    wcat = torch.randn(n, 9 * c1 + c2, generator=g) / 30
+    x1 = a1.reshape(B, hh, ww, c1).permute(0, 3, 1, 2)
+    ref3 = (F.conv2d(x1.double(), wcat[:, :9 * c1].reshape(n, 3, 3, c1).permute(0, 3, 1, 2).double(), padding=1)
+            .permute(0, 2, 3, 1).reshape(m, n) + a2.double() @ wcat[:, 9 * c1:].double().t() + bias.double())
+    out3, _ = run_gemm([(planes_of(a1.to(DEV)), c1, 9, torch.from_numpy(tab).to(DEV), hw),
+                        (planes_of(a2.to(DEV)), c2, 1, None, 0)], wcat.to(DEV), m, hw, bias=bias.to(DEV), slab=slab)
+    assert rel_err(out3.cpu(), ref3) < 2e-5
     # label_emb gather + SiLU epilogue (time_embed.2 + label_emb[y] -> SiLU), unet.py:1551,1581,610
     table = torch.randn(11, n, generator=g)
     y = torch.tensor([3, 0, 10], dtype=torch.int64)
@@ -134,11 +159,12 @@ def test_gemm_two_sources_film_residual_and_label_rows():
     w2 = torch.randn(n, c1, generator=g) / 8
     ref2 = F.silu(a.double() @ w2.double().t() + bias.double() + table[y].double())
     out2, pl2 = run_gemm([(planes_of(a.to(DEV)), c1, 1, None, 0)], w2.to(DEV), 3, 1, bias=bias.to(DEV),
-                         resid=table.to(DEV), resid_rows=y.to(DEV), act=N.ACT_SILU, want_planes=True)
+                         resid=table.to(DEV), resid_rows=y.to(DEV), act=N.ACT_SILU, want_planes=True, slab=slab)
     assert rel_err(out2.cpu(), ref2) < 2e-5 and rel_err(unplanes(pl2).cpu(), ref2) < 2e-5
 
 
-def test_gemm_geglu_epilogue():
+@pytest.mark.parametrize("slab", SLAB)
+def test_gemm_geglu_epilogue(slab):
     g = torch.Generator().manual_seed(6)
     m, dim, inner = 200, 64, 256
     a = torch.randn(m, dim, generator=g)
@@ -147,7 +173,7 @@ def test_gemm_geglu_epilogue():
     h = a.double() @ w.double().t() + b.double()
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     out, pl = run_gemm([(planes_of(a.to(DEV)), dim, 1, None, 0)], geglu_interleave(w).to(DEV), m, 1,
-                       bias=geglu_interleave(b).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=128064)
+                       bias=geglu_interleave(b).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=128064, slab=slab)
     assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
 
 

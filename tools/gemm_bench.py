@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from worddiffusion_amd import _native as N  # noqa: E402
-from worddiffusion_amd.engine import conv_gather_table  # noqa: E402
+from worddiffusion_amd.engine import conv_gather_table, slab_order, slab_span  # noqa: E402
 
 DEV = "cuda:0"
 B = 64
@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--npass", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--slab", type=int, default=0)
+    ap.add_argument("--dbg", type=int, default=0)
     a = ap.parse_args()
     lib = N.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -48,7 +50,10 @@ def main():
         act = torch.randn(2, m, cin, device=DEV).to(torch.bfloat16)
         wt = (torch.randn(2, cout, ktot, device=DEV) / ktot ** 0.5).to(torch.bfloat16)
         bias = torch.randn(cout, device=DEV)
-        tab = torch.from_numpy(conv_gather_table(h, w, "same")[0]).to(DEV) if ntaps == 9 else None
+        tab_np = conv_gather_table(h, w, "same")[0] if ntaps == 9 else None
+        tab = torch.from_numpy(tab_np).to(DEV) if ntaps == 9 else None
+        if a.slab:
+            wt = slab_order(wt, ntaps, cin, 0)
         n_out = cout // 2 if kind == "geglu" else cout
         out = torch.empty(m, n_out, device=DEV)
         g = N.WdGemmArgs()
@@ -64,6 +69,11 @@ def main():
         g.act = N.ACT_GEGLU if kind == "geglu" else 0
         g.out_f32, g.out_ld = out.data_ptr(), n_out
         g.tile = a.tile if kind != "geglu" or a.tile else 0
+        g.dbg = a.dbg
+        if a.slab:
+            g.w_layout, g.slab_rows = 1, slab_span(tab_np, hw, hw, m)
+            if kind == "geglu" and not g.tile:
+                g.tile = 128064
         for _ in range(3):
             N.check(lib.wd_gemm(C.byref(g), st), name)
         torch.cuda.synchronize()
@@ -75,7 +85,7 @@ def main():
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.iters
         fl = 2.0 * m * cout * ktot
-        print(f"{name:12s} m={m:6d} n={cout:5d} k={ktot:5d} tile={a.tile:6d} npass={a.npass}: {us:8.1f} us  "
+        print(f"{name:12s} m={m:6d} n={cout:5d} k={ktot:5d} tile={a.tile:6d} npass={a.npass} slab={a.slab} dbg={a.dbg}: {us:8.1f} us  "
               f"{fl / us / 1e6:7.1f} TF/s algorithmic ({a.npass * fl / us / 1e6:7.1f} MFMA)", flush=True)
 
 

@@ -26,59 +26,63 @@ constexpr int BK = 32;
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` inside a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
 
-// ---- epilogue shared by both kernels.  C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// ---- epilogue shared by all kernels.  C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// All global reads of a column tile (bias once, FiLM row vector and residual for its 16 rows) are issued together
+// before the first use, so the tail costs a handful of memory round trips instead of one per output element.
 template <int TN>
 __device__ __forceinline__ void wd_epilogue(const wd_gemm_args& a, const f32x16 (&acc)[TN], const int mrow0,
                                             const int ncolbase, const int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
     const int ncol0 = ncolbase + frow;
+    const bool geglu = a.act == WD_ACT_GEGLU;
+    long rv_off[16], rs_off[16];
+    bool mok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        if (m >= a.m) continue;
-        const float* rv = nullptr;
-        if (a.rowvec) rv = a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld;
-        const float* rs = nullptr;
-        if (a.resid) rs = a.resid + (a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld;
-        if (a.act == WD_ACT_GEGLU) {
+        mok[r] = m < a.m;
+        const int mm = mok[r] ? m : 0;
+        rv_off[r] = a.rowvec ? (long)(mm / a.hw_out) * a.rowvec_ld : 0;
+        rs_off[r] = a.resid ? (a.resid_rows ? (long)a.resid_rows[mm] : (long)mm) * a.resid_ld : 0;
+    }
+    constexpr int TSTEP = 1;
 #pragma unroll
-            for (int t = 0; t + 1 < TN; t += 2) {
-                const int nx = ncol0 + t * 32, ng = nx + 32;
-                const int no = (ncolbase >> 1) + (t >> 1) * 32 + frow;
-                if (ng >= a.n) continue;
-                float x = acc[t][r], g = acc[t + 1][r];
-                if (a.bias) {
-                    x += a.bias[nx];
-                    g += a.bias[ng];
-                }
-                float v = x * wd_gelu_erf(g);
-                if (rv) v += rv[no];
-                if (rs) v += rs[no];
-                if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
-                if (a.out_hi) {
-                    uint32_t h, l;
-                    wd_split1(v, h, l);
-                    a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)h;
-                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)l;
-                }
-            }
-        } else {
+    for (int t = 0; t < TN; t += TSTEP) {
+        if (geglu && (t & 1)) continue;  // gate tiles are consumed together with their x tile
+        const int nx = ncol0 + t * 32;            // column in the accumulator / bias index space
+        const int ng = nx + 32;                   // GEGLU gate column
+        const int no = geglu ? (ncolbase >> 1) + (t >> 1) * 32 + frow : nx;  // output column
+        const bool nok = geglu ? (ng < a.n) : (nx < a.n);
+        float bx = 0.f, bg = 0.f;
+        if (a.bias && nok) {
+            bx = a.bias[nx];
+            if (geglu) bg = a.bias[ng];
+        }
+        float rvv[16], rsv[16];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const int n = ncol0 + t * 32;
-                if (n >= a.n) continue;
-                float v = acc[t][r];
-                if (a.bias) v += a.bias[n];
-                if (rv) v += rv[n];
-                if (rs) v += rs[n];
+        for (int r = 0; r < 16; ++r) {
+            rvv[r] = (a.rowvec && nok && mok[r]) ? a.rowvec[rv_off[r] + no] : 0.f;
+            rsv[r] = (a.resid && nok && mok[r]) ? a.resid[rs_off[r] + no] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!(nok && mok[r])) continue;
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            float v;
+            if (geglu) {
+                const float x = acc[t][r] + bx;
+                const float g = acc[(t + 1 < TN) ? t + 1 : t][r] + bg;
+                v = x * wd_gelu_erf(g) + rvv[r] + rsv[r];
+            } else {
+                v = acc[t][r] + bx + rvv[r] + rsv[r];
                 if (a.act == WD_ACT_SILU) v = wd_silu(v);
-                if (a.out_f32) a.out_f32[(long)m * a.out_ld + n] = v;
-                if (a.out_hi) {
-                    uint32_t h, l;
-                    wd_split1(v, h, l);
-                    a.out_hi[(long)m * a.out_pl_ld + n] = (wd_bf16)h;
-                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + n] = (wd_bf16)l;
-                }
+            }
+            if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
+            if (a.out_hi) {
+                uint32_t h, l;
+                wd_split1(v, h, l);
+                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)h;
+                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)l;
             }
         }
     }
@@ -262,6 +266,128 @@ __global__ void __launch_bounds__(256, 2) wd_gemm_kernel(const wd_gemm_args a, c
     wd_epilogue<TN>(a, acc, m0 + wm * 32, n0 + wn * WCOLS, lane);
 }
 
+// ---- vectorised epilogue for the v2 / v3 kernels: the accumulators of all waves go through an fp32 LDS image of
+// the output tile (which also sums the two k-halves of the 8-wave variants), then every thread reads float4s
+// row-major and does bias / FiLM / residual / activation with 16-byte global loads and stores.
+template <int BM, int BN, int TN, int NT>
+__device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32x16 (&acc)[TN], char* smem, const int m0,
+                                                const int n0, const int wm, const int wn, const int wcols, const int kh,
+                                                const int nkh, const int tid) {
+    constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
+    float* ep = reinterpret_cast<float*>(smem);
+    const int lane = tid & 63;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with the operand buffers
+    for (int h = 0; h < nkh; ++h) {
+        if (kh == h) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* p = ep + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * LDE + wn * wcols + t * 32 + frow;
+                    *p = (h == 0) ? acc[t][r] : *p + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    const bool geglu = a.act == WD_ACT_GEGLU;
+    const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
+    const int oc4 = ocols / 4;
+    const int nout = geglu ? a.n / 2 : a.n;
+    const int no0 = geglu ? n0 / 2 : n0;
+    // 16-byte path needs aligned rows everywhere; otherwise (odd leading dimensions) one element at a time
+    const bool vec = (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
+                        reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32)) & 15) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0);
+    if (!vec) {
+        for (int i = tid; i < BM * ocols; i += NT) {
+            const int row = i / ocols, c = i - row * ocols;
+            const int m = m0 + row, no = no0 + c;
+            if (m >= a.m || no >= nout) continue;
+            float v;
+            if (geglu) {
+                const int ec = (c >> 5) * 64 + (c & 31);
+                const float x = ep[row * LDE + ec] + (a.bias ? a.bias[n0 + ec] : 0.f);
+                const float g = ep[row * LDE + ec + 32] + (a.bias ? a.bias[n0 + ec + 32] : 0.f);
+                v = x * wd_gelu_erf(g);
+            } else {
+                v = ep[row * LDE + c] + (a.bias ? a.bias[no] : 0.f);
+            }
+            if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
+            if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
+            if (a.act == WD_ACT_SILU) v = wd_silu(v);
+            if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
+            if (a.out_hi) {
+                uint32_t hb, lb;
+                wd_split1(v, hb, lb);
+                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
+                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)lb;
+            }
+        }
+        return;
+    }
+    for (int i = tid; i < BM * oc4; i += NT) {
+        const int row = i / oc4, c = (i - row * oc4) * 4;
+        const int m = m0 + row, no = no0 + c;
+        if (m >= a.m || no >= nout) continue;
+        float4 v;
+        if (geglu) {
+            const int ec = (c >> 5) * 64 + (c & 31);
+            const float4 x = *reinterpret_cast<const float4*>(ep + row * LDE + ec);
+            const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + ec + 32);
+            float4 bx = make_float4(0, 0, 0, 0), bg = bx;
+            if (a.bias) {
+                bx = *reinterpret_cast<const float4*>(a.bias + n0 + ec);
+                bg = *reinterpret_cast<const float4*>(a.bias + n0 + ec + 32);
+            }
+            v.x = (x.x + bx.x) * wd_gelu_erf(g.x + bg.x);
+            v.y = (x.y + bx.y) * wd_gelu_erf(g.y + bg.y);
+            v.z = (x.z + bx.z) * wd_gelu_erf(g.z + bg.z);
+            v.w = (x.w + bx.w) * wd_gelu_erf(g.w + bg.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + no);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+        }
+        if (a.rowvec) {
+            const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (a.resid) {
+            const long rr = a.resid_rows ? (long)a.resid_rows[m] : (long)m;
+            const float4 q = *reinterpret_cast<const float4*>(a.resid + rr * a.resid_ld + no);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (a.act == WD_ACT_SILU) {
+            v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
+        }
+        if (no + 3 < nout) {
+            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
+            if (a.out_hi) {
+                uint2 hh, ll;
+                wd_split4(v, hh, ll);
+                *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
+                if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + no) = ll;
+            }
+        } else {  // ragged right edge (n not a multiple of 4 columns inside this float4)
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4 && no + j < nout; ++j) {
+                if (a.out_f32) a.out_f32[(long)m * a.out_ld + no + j] = e[j];
+                if (a.out_hi) {
+                    uint32_t hb, lb;
+                    wd_split1(e[j], hb, lb);
+                    a.out_hi[(long)m * a.out_pl_ld + no + j] = (wd_bf16)hb;
+                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no + j] = (wd_bf16)lb;
+                }
+            }
+        }
+    }
+}
+
 // ======================================================================================================
 // v2: BK = 64, operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging), two LDS stages,
 // one barrier per K-step: the loads of step k+1 are in flight while step k is multiplied.  Full 128-byte lines
@@ -277,19 +403,24 @@ typedef __attribute__((address_space(1))) const void* wd_gbl_ptr;
 
 __device__ __forceinline__ int lds_off2(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
-template <int BM, int BN, int NPASS>
-__global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+// KS = 1: 4 waves, each owns a 32 x (BN / WN) output tile for the whole K range.
+// KS = 2: 8 waves; waves 4..7 shadow waves 0..3 on the same output tile but multiply the second half of every
+//         64-deep stage (k-steps 2,3), so each SIMD hosts two independent MFMA / ds_read streams that cover each
+//         other's LDS latency; the two partial accumulators are summed once through LDS before the epilogue.
+template <int BM, int BN, int NPASS, int KS>
+__global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int NW = 4 * KS;
     constexpr int WM = BM / 32, WN = 4 / WM;
     constexpr int WCOLS = BN / WN;
     constexpr int TN = WCOLS / 32;
     static_assert(WCOLS % 32 == 0 && WM * WN == 4, "bad tile");
-    constexpr int A_INS = BM / 32;  // 8-row DMA pieces per plane per wave
-    constexpr int B_INS = BN / 32;
-    static_assert(BM % 32 == 0 && BN % 32 == 0, "bad tile");
+    constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;       // 8-row DMA pieces per plane
+    constexpr int A_INS = (A_PIECES + NW - 1) / NW, B_INS = (B_PIECES + NW - 1) / NW;
     constexpr int A_PL = BM * 128;
     constexpr int B_PL = BN * 128;
     constexpr int STAGE = NPL * (A_PL + B_PL);
+    constexpr int KK_PER = 4 / KS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE);  // [ntaps0][BM] source row of src[0] per tap, -1 = zero row
@@ -307,7 +438,8 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wq = wave & 3, kh = wave >> 2;
+    const int wm = wq / WN, wn = wq % WN;
     const int lrow = lane >> 3, lpos = lane & 7;
 
     // ---- source-row table of src[0] for this row panel (one global gather lookup per (tap, row), done once)
@@ -315,7 +447,7 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
         const int nt0 = a.src[0].ntaps;
         const int32_t* g0 = a.src[0].gather;
         const int hw_src0 = a.src[0].hw_src;
-        for (int idx = tid; idx < nt0 * BM; idx += 256) {
+        for (int idx = tid; idx < nt0 * BM; idx += 256 * KS) {
             const int t = idx / BM, row = idx - t * BM;
             const int m = m0 + row;
             int v = -1;
@@ -333,20 +465,20 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
     }
     __syncthreads();
 
-    // ---- the rows this lane feeds (A_INS pieces of 8 rows per plane for A, B_INS for W)
+    // ---- the rows this lane feeds: piece (wave + NW * i) of 8 rows, for A and for W
     int a_sw[A_INS];
 #pragma unroll
     for (int i = 0; i < A_INS; ++i) {
-        const int row = wave * (BM / 4) + 8 * i + lrow;
+        const int row = (wave + NW * i) * 8 + lrow;
         a_sw[i] = (lpos ^ ((row >> 1) & 7)) * 8;  // source chunk (in elements) that lands at position lpos
     }
     long b_off[B_INS];
     bool b_ok[B_INS];
 #pragma unroll
     for (int i = 0; i < B_INS; ++i) {
-        const int row = wave * (BN / 4) + 8 * i + lrow;
+        const int row = (wave + NW * i) * 8 + lrow;
         const int n = n0 + row;
-        b_ok[i] = n < a.n;
+        b_ok[i] = (row < BN) && (n < a.n);
         b_off[i] = (long)n * a.ktot + (lpos ^ ((row >> 1) & 7)) * 8;
     }
     const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
@@ -360,34 +492,42 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
     auto locate = [&]() {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
-            const int row = wave * (BM / 4) + 8 * i + lrow;
-            int r;
-            if (s == 0) r = s_tab[tap * BM + row];
-            else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
+            const int row = (wave + NW * i) * 8 + lrow;
+            int r = -1;
+            if (row < BM) {
+                if (s == 0) r = s_tab[tap * BM + row];
+                else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
+            }
             a_off[i] = r >= 0 ? (long)r * cur_ld + a_sw[i] : -1;
         }
     };
     locate();
 
     auto issue = [&](int kit, int stage) {
-        char* base = smem + stage * STAGE + wave * (BM / 4) * 128;
+        char* sbase = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
-            const wd_bf16* ph = a_off[i] >= 0 ? cur_hi + a_off[i] + kc * BK2 : zline;
-            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(base + i * 1024), 16, 0, 0);
-            if (NPL == 2) {
-                const wd_bf16* pl = a_off[i] >= 0 ? cur_lo + a_off[i] + kc * BK2 : zline;
-                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(base + A_PL + i * 1024), 16, 0, 0);
+            const int piece = wave + NW * i;  // wave-uniform
+            if (piece < A_PIECES) {
+                const wd_bf16* ph = a_off[i] >= 0 ? cur_hi + a_off[i] + kc * BK2 : zline;
+                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(sbase + piece * 1024), 16, 0, 0);
+                if (NPL == 2) {
+                    const wd_bf16* pl = a_off[i] >= 0 ? cur_lo + a_off[i] + kc * BK2 : zline;
+                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(sbase + A_PL + piece * 1024), 16, 0, 0);
+                }
             }
         }
-        char* bb = smem + stage * STAGE + NPL * A_PL + wave * (BN / 4) * 128;
+        char* bb = sbase + NPL * A_PL;
 #pragma unroll
         for (int i = 0; i < B_INS; ++i) {
-            const wd_bf16* ph = b_ok[i] ? a.w_hi + b_off[i] + (long)kit * BK2 : zline;
-            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(bb + i * 1024), 16, 0, 0);
-            if (NPL == 2) {
-                const wd_bf16* pl = b_ok[i] ? a.w_lo + b_off[i] + (long)kit * BK2 : zline;
-                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(bb + B_PL + i * 1024), 16, 0, 0);
+            const int piece = wave + NW * i;
+            if (piece < B_PIECES) {
+                const wd_bf16* ph = b_ok[i] ? a.w_hi + b_off[i] + (long)kit * BK2 : zline;
+                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(bb + piece * 1024), 16, 0, 0);
+                if (NPL == 2) {
+                    const wd_bf16* pl = b_ok[i] ? a.w_lo + b_off[i] + (long)kit * BK2 : zline;
+                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(bb + B_PL + piece * 1024), 16, 0, 0);
+                }
             }
         }
     };
@@ -422,21 +562,6 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
     advance();
 
     const int frow = lane & 31, fhalf = lane >> 5;
-    // fragment registers, double buffered over the four 16-deep k-steps of a stage
-    bf16x8 fa[2][NPL], fb[2][TN][NPL];
-    auto lfrag = [&](const char* base, int kk, int set) {
-        const int ch = kk * 2 + fhalf;
-        const int ao = lds_off2(wm * 32 + frow, ch);
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) fa[set][p] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + ao);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const int bo = NPL * A_PL + lds_off2(wn * WCOLS + t * 32 + frow, ch);
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) fb[set][t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
-        }
-    };
-
     for (int kit = 0; kit < nk; ++kit) {
         __syncthreads();  // vmcnt(0) + barrier: step kit has landed, everybody is done reading the other stage
         if (kit + 1 < nk) {
@@ -444,23 +569,329 @@ __global__ void __launch_bounds__(256, 1) wd_gemm2_kernel(const wd_gemm_args a, 
             advance();
         }
         const char* base = smem + (kit & 1) * STAGE;
-        lfrag(base, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1;
-            if (kk < 3) lfrag(base, kk + 1, cur ^ 1);
+        for (int k2 = 0; k2 < KK_PER; ++k2) {
+            const int kk = kh * KK_PER + k2;
+            const int ch = kk * 2 + fhalf;
+            const int ao = lds_off2(wm * 32 + frow, ch);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + ao);
+            bf16x8 al;
+            if (NPL == 2) al = *reinterpret_cast<const bf16x8*>(base + A_PL + ao);
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
+                const int bo = NPL * A_PL + lds_off2(wn * WCOLS + t * 32 + frow, ch);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(base + bo);
                 if (NPL == 2) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][NPL - 1], fb[cur][t][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][NPL - 1], acc[t], 0, 0, 0);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(base + B_PL + bo);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
         }
     }
 
-    wd_epilogue<TN>(a, acc, m0 + wm * 32, n0 + wn * WCOLS, lane);
+    wd_epilogue_lds<BM, BN, TN, 256 * KS>(a, acc, smem, m0, n0, wm, wn, WCOLS, kh, KS, tid);
+}
+
+// ======================================================================================================
+// v3 "slab" kernel: the A operand of a 3x3 convolution is NOT re-fetched per tap.  For a panel of BM output rows
+// the union of source rows over all taps is a short contiguous range (a few image rows + halo): that slab is
+// DMA'd into LDS once per 32-channel chunk (double buffered, prefetched one chunk ahead) and all nine taps read
+// their shifted A fragments from it through a per-(tap,row) LDS table.  Only the weights stream per tap, through
+// a 4-deep LDS ring kept full with counted s_waitcnt vmcnt(N) + raw s_barrier (no full drain in the loop).
+// Weights are stored in consumption order [chunk][tap][N][32] so that one stage is one contiguous block.
+// L2->LDS bytes per MFMA drop ~2.8x against v2; linears (one tap) run through the same code.
+constexpr int CK3 = 32;
+constexpr int RING3 = 4;
+
+__device__ __forceinline__ void wd_wait_vmcnt(int n) {  // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // stricter than needed, still correct
+    }
+}
+
+template <int BM, int BN, int NPASS, int SLABR, int KS>
+__global__ void __launch_bounds__(256 * KS, 1) wd_gemm3_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int NW = 4 * KS, NT = 256 * KS;
+    constexpr int WM = BM / 32, WN = 4 / WM;
+    constexpr int WCOLS = BN / WN;
+    constexpr int TN = WCOLS / 32;
+    static_assert(WCOLS % 32 == 0 && WM * WN == 4, "bad tile");
+    constexpr int SLAB_PL = (SLABR + 1) * 64;          // one plane of one slab buffer (+ the all-zero row)
+    constexpr int SLAB_BUF = NPL * SLAB_PL;
+    constexpr int W_PL = BN * 64;
+    constexpr int W_SLOT = NPL * W_PL;
+    constexpr int OFF_RING = 2 * SLAB_BUF;
+    constexpr int OFF_TAB = OFF_RING + RING3 * W_SLOT;
+    constexpr int W_PIECES = NPL * (BN / 16);            // 1 KB DMA pieces per W stage
+    constexpr int W_INS = (W_PIECES + NW - 1) / NW;
+    constexpr int S_PIECES_MAX = NPL * ((SLABR + 15) / 16);
+    constexpr int S_INS = (S_PIECES_MAX + NW - 1) / NW;
+    constexpr int KK_PER = 2 / KS;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_tab = reinterpret_cast<int*>(smem + OFF_TAB);   // [ntaps0][BM] slab-local row, SLABR = zero row
+    int* s_misc = s_tab + 9 * BM;                          // [0] = min source row of the panel
+
+    const int nwg = nbn * nbm;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bn_i = wg % nbn, bm_i = wg / nbn;
+    const int m0 = bm_i * BM, n0 = bn_i * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, kh = wave >> 2;
+    const int wm = wq / WN, wn = wq % WN;
+    const int prow = lane >> 2, ppos = lane & 3;  // row / 16-byte position of this lane inside a 16-row DMA piece
+
+    const int dbg = a.dbg;  // timing-only ablation switches (tools/gemm_bench.py --dbg), 0 in production
+    const int nt0 = a.src[0].ntaps;
+    const int c0chunks = a.src[0].c / CK3;
+    const int c1chunks = a.nsrc > 1 ? a.src[1].c / CK3 : 0;
+    const int nstage = (dbg & 32) ? 0 : c0chunks * nt0 + c1chunks;
+    if (dbg & 128) return;
+
+    // ---- table of source rows, panel minimum, zero rows
+    if (tid == 0) s_misc[0] = 0x7fffffff;
+    for (int i = tid; i < 2 * NPL * 16; i += NT) {  // the zero row of every slab buffer / plane (64 B each)
+        const int which = i >> 4, w = i & 15;
+        reinterpret_cast<int*>(smem + which * SLAB_PL + SLABR * 64)[w] = 0;
+    }
+    __syncthreads();
+    {
+        const int32_t* g0 = a.src[0].gather;
+        const int hw_src0 = a.src[0].hw_src;
+        int mn = 0x7fffffff;
+        for (int idx = tid; idx < nt0 * BM; idx += NT) {
+            const int t = idx / BM, row = idx - t * BM;
+            const int m = m0 + row;
+            int v = -1;
+            if (m < a.m) {
+                if (g0) {
+                    const int b = m / a.hw_out, p = m - b * a.hw_out;
+                    const int g = g0[t * a.hw_out + p];
+                    if (g >= 0) v = b * hw_src0 + g;
+                } else {
+                    v = m;
+                }
+            }
+            s_tab[idx] = v;
+            if (v >= 0) mn = min(mn, v);
+        }
+        atomicMin(&s_misc[0], mn);
+    }
+    __syncthreads();
+    const int rlo = s_misc[0];
+    for (int idx = tid; idx < nt0 * BM; idx += NT) {
+        const int v = s_tab[idx];
+        int l = SLABR;
+        if (v >= 0 && v - rlo < SLABR) l = v - rlo;  // (span is validated by the host; out-of-span rows read zeros)
+        s_tab[idx] = l;
+    }
+    // rows of src[0] present in the slab: [rlo, rlo + span0); src[1] (identity): [m0, m0 + BM)
+    const int span0 = min(SLABR, a.slab_rows);
+    const long rows0 = (long)((a.src[0].gather ? (long)((a.m + a.hw_out - 1) / a.hw_out) * a.src[0].hw_src : (long)a.m));
+    const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + ppos * 8;
+
+    // DMA bookkeeping (all wave-uniform scalars): `issued` counts this wave's glds; mw0..mw3 are the values of
+    // `issued` right after the W stages st, st+1, st+2, st+3 were issued; ms_cur / ms_nxt the same for the slab of
+    // the current / next phase.  s_waitcnt vmcnt(issued - mark) == "everything up to that issue has landed".
+    int issued = 0;
+    int mw0 = 0, mw1 = 0, mw2 = 0, mw3 = 0;
+    int ms_cur = 0, ms_nxt = 0;
+
+    // slab of phase ph (source, chunk) -> buffer ph & 1
+    auto issue_slab = [&](int ph) {
+        const bool s1 = ph >= c0chunks;
+        const int chunk = s1 ? ph - c0chunks : ph;
+        const wd_bf16* hi = s1 ? a.src[1].hi : a.src[0].hi;
+        const wd_bf16* lo = s1 ? a.src[1].lo : a.src[0].lo;
+        const int ld = s1 ? a.src[1].ld : a.src[0].ld;
+        const long base_row = s1 ? m0 : rlo;
+        const int span = s1 ? BM : span0;
+        const long row_lim = s1 ? (long)a.m : rows0;
+        const int npieces = NPL * ((span + 15) / 16);
+        char* sb = smem + (ph & 1) * SLAB_BUF;
+#pragma unroll
+        for (int i = 0; i < S_INS; ++i) {
+            const int piece = wave + NW * i;  // wave-uniform
+            if (piece < npieces) {
+                const int pl = (NPL == 2) ? (piece & 1) : 0;
+                const int rp = (NPL == 2) ? (piece >> 1) : piece;
+                const int r = rp * 16 + prow;                       // slab row
+                const long gr = base_row + r;
+                const wd_bf16* src = (pl ? lo : hi);
+                const wd_bf16* ptr = (r < span && gr < row_lim)
+                                         ? src + gr * ld + chunk * CK3 + ((ppos ^ ((r >> 2) & 3)) << 3)
+                                         : zline;
+                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ptr, (wd_lds_ptr)(sb + pl * SLAB_PL + rp * 1024), 16, 0, 0);
+                ++issued;
+            }
+        }
+        ms_nxt = issued;
+    };
+    // W stage st (consumption order) -> ring slot st % RING3.  Global block st: [N][32] per plane, contiguous.
+    auto issue_w = [&](int st) {
+        char* rb = smem + OFF_RING + (st % RING3) * W_SLOT;
+        const long blk = (long)st * a.n * CK3;
+#pragma unroll
+        for (int i = 0; i < W_INS; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < W_PIECES) {
+                const int pl = (NPL == 2) ? (piece & 1) : 0;
+                const int rp = (NPL == 2) ? (piece >> 1) : piece;
+                const int r = rp * 16 + prow;  // row inside the BN tile
+                const int n = n0 + r;
+                const wd_bf16* src = pl ? a.w_lo : a.w_hi;
+                const wd_bf16* ptr = (n < a.n) ? src + blk + (long)n * CK3 + ((ppos ^ ((r >> 2) & 3)) << 3) : zline;
+                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ptr, (wd_lds_ptr)(rb + pl * W_PL + rp * 1024), 16, 0, 0);
+                ++issued;
+            }
+        }
+        mw3 = issued;
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    __syncthreads();  // table finalised (also orders the zero-row writes before any fragment read)
+    issue_slab(0);
+    ms_cur = ms_nxt;
+    if (0 < nstage) { issue_w(0); mw0 = mw3; }
+    if (1 < nstage) { issue_w(1); mw1 = mw3; }
+    if (2 < nstage) { issue_w(2); mw2 = mw3; }
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int arow = wm * 32 + frow;
+    int ph = 0, tap = 0;       // phase / tap of the current stage
+    int ntap_ph = nt0;         // taps in the current phase
+    auto next_stage = [&]() {
+        mw0 = mw1;
+        mw1 = mw2;
+        mw2 = mw3;
+        if (++tap == ntap_ph) {
+            tap = 0;
+            ++ph;
+            ntap_ph = ph < c0chunks ? nt0 : 1;
+            ms_cur = ms_nxt;
+        }
+    };
+    for (int st = 0; st < nstage; ++st) {
+        // ---- wait until stage st's weights and its phase's slab have landed (everything younger may stay in flight)
+        wd_wait_vmcnt(issued - max(mw0, ms_cur));
+        if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- refill: the slot of stage st-1 and (at a phase start) the other slab buffer are free now
+        if (tap == 0 && ph + 1 < c0chunks + c1chunks && !(dbg & 8)) issue_slab(ph + 1);
+        if (st + RING3 - 1 < nstage && !(dbg & 4)) issue_w(st + RING3 - 1);
+
+        // ---- multiply stage st
+        const char* sb = smem + (ph & 1) * SLAB_BUF;
+        const char* rb = smem + OFF_RING + (st % RING3) * W_SLOT;
+        int idx;
+        if (ph < c0chunks) idx = s_tab[tap * BM + arow];
+        else idx = (m0 + arow < a.m) ? arow : SLABR;
+        const int abase = idx * 64, asw = (idx >> 2) & 3;
+        // all fragments of this wave's k-steps first (the MFMAs then drain them behind counted lgkmcnt waits) ...
+        bf16x8 fa[KK_PER][NPL], fb[KK_PER][TN][NPL];
+        if (dbg & 2) { next_stage(); continue; }
+#pragma unroll
+        for (int k2 = 0; k2 < KK_PER; ++k2) {
+            const int ch = (kh * KK_PER + k2) * 2 + fhalf;
+            const int ao = abase + ((ch ^ asw) << 4);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) fa[k2][p] = *reinterpret_cast<const bf16x8*>(sb + p * SLAB_PL + ao);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int bo = lds_off(wn * WCOLS + t * 32 + frow, ch);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) fb[k2][t][p] = *reinterpret_cast<const bf16x8*>(rb + p * W_PL + bo);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg & 1) {
+#pragma unroll
+            for (int k2 = 0; k2 < KK_PER; ++k2) {
+                asm volatile("" ::"v"(fa[k2][0]), "v"(fa[k2][NPL - 1]));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) asm volatile("" ::"v"(fb[k2][t][0]), "v"(fb[k2][t][NPL - 1]));
+            }
+            next_stage();
+            continue;
+        }
+        // ... then the multiply block
+#pragma unroll
+        for (int k2 = 0; k2 < KK_PER; ++k2) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (NPL == 2) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][NPL - 1], fb[k2][t][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][0], fb[k2][t][NPL - 1], acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][0], fb[k2][t][0], acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        next_stage();
+    }
+    if (dbg & 64) {
+        if (acc[0][0] == 123.456f) a.out_f32[0] = acc[0][1];
+        return;
+    }
+    wd_epilogue_lds<BM, BN, TN, NT>(a, acc, smem, m0, n0, wm, wn, WCOLS, kh, KS, tid);
+}
+
+template <int BM, int BN, int NPASS, int SLABR, int KS>
+int launch3(const wd_gemm_args& a, hipStream_t st) {
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int loop_smem = 2 * NPL * (SLABR + 1) * 64 + RING3 * NPL * BN * 64 + 9 * BM * 4 + 64;
+    constexpr int red_smem = BM * (BN + 4) * 4;
+    constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm3_kernel<BM, BN, NPASS, SLABR, KS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return WD_ELAUNCH;
+        attr_done = true;
+    }
+    const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
+    WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+    hipLaunchKernelGGL((wd_gemm3_kernel<BM, BN, NPASS, SLABR, KS>), dim3(nbn * nbm), dim3(256 * KS), smem, st, a, nbn,
+                       nbm);
+    return wd_check_launch();
 }
 
 template <int BM, int BN, int NPASS>
@@ -480,20 +911,22 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
-template <int BM, int BN, int NPASS>
+template <int BM, int BN, int NPASS, int KS>
 int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
-    constexpr int smem = 2 * NPL * (BM + BN) * 128 + 9 * BM * 4;
+    constexpr int loop_smem = 2 * NPL * (BM + BN) * 128 + 9 * BM * 4;
+    constexpr int red_smem = BM * (BN + 4) * 4;  // the fp32 epilogue image overlays the stage buffers
+    constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS, KS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return WD_ELAUNCH;
         attr_done = true;
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
     WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS>), dim3(nbn * nbm), dim3(256), smem, st, a, nbn, nbm);
+    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS>), dim3(nbn * nbm), dim3(256 * KS), smem, st, a, nbn, nbm);
     return wd_check_launch();
 }
 
@@ -520,6 +953,26 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.resid && a.resid_ld <= 0) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+    if (a.w_layout == 1) {
+        // slab-order weights: v3 kernel only.  Contract: c % 32 == 0 (checked above), src[1] identity, slab_rows set.
+        if (a.src[0].ntaps > 9 || a.slab_rows <= 0) return WD_EINVAL;
+        if (a.nsrc == 2 && (a.src[1].gather || a.src[1].ntaps != 1)) return WD_EINVAL;
+        int t3 = a.tile;
+        if (t3 == 0) t3 = (a.act == WD_ACT_GEGLU || a.n % 160) ? 128064 : 128160;
+        if (a.act == WD_ACT_GEGLU && t3 != 128064 && t3 != 128128) return WD_EINVAL;
+        if (a.slab_rows > 192) return WD_EINVAL;
+        static const int ks3_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
+#define WD_DISPATCH3(BM_, BN_)                                                                                   \
+    if (ks3_env == 1) return a.npass == 3 ? launch3<BM_, BN_, 3, 192, 1>(a, st) : launch3<BM_, BN_, 1, 192, 1>(a, st); \
+    return a.npass == 3 ? launch3<BM_, BN_, 3, 192, 2>(a, st) : launch3<BM_, BN_, 1, 192, 2>(a, st)
+        switch (t3) {
+            case 128064: WD_DISPATCH3(128, 64);
+            case 128128: WD_DISPATCH3(128, 128);
+            case 128160: WD_DISPATCH3(128, 160);
+            default: return WD_EINVAL;
+        }
+#undef WD_DISPATCH3
+    }
     int tile = a.tile;
     if (tile == 0) {
         // heuristics: keep >= ~1 workgroup per CU; GEGLU pairs column tiles inside one wave (needs 128x64 / 64x64 ...)
@@ -529,16 +982,20 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         else if ((long)((a.m + 127) / 128) * ((a.n + 63) / 64) >= 192) tile = 128064;
         else tile = (a.m > 64 * 2) ? 64064 : 128064;
     }
-    if (a.act == WD_ACT_GEGLU && tile != 128064) return WD_EINVAL;
+    if (a.act == WD_ACT_GEGLU && tile != 128064 && tile != 128128) return WD_EINVAL;
     bool v2ok = (a.ktot % BK2 == 0) && !getenv("WDIFF_GEMM_V1");
+    static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
+    const int ks = ks_env == 1 ? 1 : 2;
     for (int s = 0; s < a.nsrc; ++s) v2ok = v2ok && (a.src[s].c % BK2 == 0);
     v2ok = v2ok && a.src[0].ntaps <= 9 && (a.nsrc == 1 || (a.src[1].gather == nullptr && a.src[1].ntaps == 1));
 #define WD_DISPATCH(BM_, BN_)                                                                      \
-    if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3>(a, st) : launch2<BM_, BN_, 1>(a, st); \
+    if (v2ok && ks == 2) return a.npass == 3 ? launch2<BM_, BN_, 3, 2>(a, st) : launch2<BM_, BN_, 1, 2>(a, st); \
+    if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3, 1>(a, st) : launch2<BM_, BN_, 1, 1>(a, st); \
     return a.npass == 3 ? launch<BM_, BN_, 3>(a, st) : launch<BM_, BN_, 1>(a, st)
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);
         case 128160: WD_DISPATCH(128, 160);
+        case 128128: WD_DISPATCH(128, 128);
         case 64064: WD_DISPATCH(64, 64);
         default: return WD_EINVAL;
     }

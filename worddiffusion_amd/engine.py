@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -70,6 +71,39 @@ def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([x, g], dim=1).reshape(w.shape)
 
 
+def slab_order(wp: torch.Tensor, ntaps0: int, c0: int, c1: int = 0) -> torch.Tensor:
+    """[..., N, ktot] (k = tap-major/channel-minor of src0, then src1) -> "slab order" [..., stages, N, 32]:
+    stage = (32-channel chunk of src0, tap) chunk-major, then the 32-channel chunks of src1 (wd_gemm w_layout 1)."""
+    lead = wp.shape[:-2]
+    n = wp.shape[-2]
+    k0 = ntaps0 * c0
+    w0 = wp[..., :k0].reshape(*lead, n, ntaps0, c0 // 32, 32)
+    nl = len(lead)
+    w0 = w0.permute(*range(nl), nl + 2, nl + 1, nl, nl + 3).reshape(*lead, (c0 // 32) * ntaps0, n, 32)
+    if c1:
+        w1 = wp[..., k0:].reshape(*lead, n, c1 // 32, 32).permute(*range(nl), nl + 1, nl, nl + 2)
+        w0 = torch.cat([w0, w1], dim=nl)
+    return w0.contiguous()
+
+
+def slab_span(tab: Optional[np.ndarray], hw_out: int, hw_src: int, m: int, bm: int = 128) -> int:
+    """Largest (max - min + 1) of the gathered source rows over the bm-row output panels (wd_gemm slab_rows)."""
+    if tab is None:
+        return bm
+    period = int(np.lcm(bm, hw_out))
+    mt = min(m, 2 * period)
+    rows = np.arange(mt)
+    b, p = rows // hw_out, rows % hw_out
+    src = np.where(tab[:, p] >= 0, b[None, :] * hw_src + tab[:, p], -1)  # [ntaps, mt]
+    span = 0
+    for r0 in range(0, mt, bm):
+        blk = src[:, r0:r0 + bm]
+        valid = blk[blk >= 0]
+        if valid.size:
+            span = max(span, int(valid.max() - valid.min() + 1))
+    return span
+
+
 class Act:
     """A token-major fp32 feature map [B*h*w, c] on the device."""
     __slots__ = ("t", "c", "h", "w")
@@ -113,8 +147,12 @@ class UNetEngine:
         self.npass = 3
         self._sig = None
         self._w: Dict[str, torch.Tensor] = {}
+        self._w3: Dict[str, torch.Tensor] = {}      # slab-order copies of the matrices the v3 kernel consumes
+        self._w3_meta: Dict[str, tuple] = {}
+        self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
+        self._tab_np: Dict[int, np.ndarray] = {}
         self.device = None
 
     # ------------------------------------------------------------------------------------------ weights
@@ -257,8 +295,11 @@ class UNetEngine:
                                 "(there is no CPU / eager fallback)")
         if self.device is not None and dev != self.device:
             self._w.clear()
+            self._w3.clear()
+            self._w3_meta.clear()
             self._plans.clear()
             self._tabs.clear()
+            self._tab_np.clear()
         self.device = dev
         with torch.no_grad():
             for name, fn in self._recipes().items():
@@ -276,6 +317,8 @@ class UNetEngine:
                     if name not in self._w:
                         self._w[name] = torch.empty_like(src)
                     self._w[name].copy_(src)
+            for name, meta in self._w3_meta.items():
+                self._w3[name].copy_(slab_order(self._w[name], *meta))
             if "freqs" not in self._w:
                 half = self.model.model_channels // 2
                 freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
@@ -288,7 +331,9 @@ class UNetEngine:
         key = (h, w, mode)
         if key not in self._tabs:
             tab, ho, wo = conv_gather_table(h, w, mode)
-            self._tabs[key] = (torch.from_numpy(tab).to(self.device), ho, wo)
+            dt = torch.from_numpy(tab).to(self.device)
+            self._tabs[key] = (dt, ho, wo)
+            self._tab_np[dt.data_ptr()] = tab
         return self._tabs[key]
 
     def _f32(self, P: Plan, *shape):
@@ -304,6 +349,7 @@ class UNetEngine:
     def _src(self, planes: torch.Tensor, c: int, ntaps: int = 1, gather: Optional[torch.Tensor] = None,
              hw_src: int = 0, col_off: int = 0) -> N.WdSrc:
         s = N.WdSrc()
+        s._tab_np = self._tab_np.get(gather.data_ptr()) if gather is not None else None
         ld = planes.shape[2]
         s.hi = planes[0].data_ptr() + 2 * col_off
         s.lo = planes[1].data_ptr() + 2 * col_off
@@ -322,9 +368,28 @@ class UNetEngine:
         wp = self._w[wname]
         ktot = wp.shape[2]
         assert ktot == sum(s.ntaps * s.c for s in srcs), (what, ktot, [(s.ntaps, s.c) for s in srcs])
-        a.w_hi = wp[0].data_ptr() + 2 * w_row_off * ktot
-        a.w_lo = wp[1].data_ptr() + 2 * w_row_off * ktot
-        a.m, a.n, a.ktot, a.hw_out = m, (wp.shape[1] if n is None else n), ktot, hw_out
+        nrows = wp.shape[1] if n is None else n
+        span = 0
+        if self.use_slab and w_row_off == 0 and (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather)):
+            tabnp = getattr(srcs[0], "_tab_np", None)
+            span = slab_span(tabnp, hw_out, srcs[0].hw_src, m)
+            # the slab kernel runs 128-row panels: only worth it when they fill the chip
+            if span > 192 or ((m + 127) // 128) * max(1, nrows // 160) < 96:
+                span = 0
+        if span:
+            meta = (srcs[0].ntaps, srcs[0].c, srcs[1].c if len(srcs) > 1 else 0)
+            if wname not in self._w3:
+                self._w3[wname] = slab_order(wp, *meta)
+                self._w3_meta[wname] = meta
+            assert self._w3_meta[wname] == meta, wname
+            w3 = self._w3[wname]
+            a.w_hi, a.w_lo = w3[0].data_ptr(), w3[1].data_ptr()
+            a.w_layout, a.slab_rows = 1, span
+            tile = 0 if tile == 0 else tile
+        else:
+            a.w_hi = wp[0].data_ptr() + 2 * w_row_off * ktot
+            a.w_lo = wp[1].data_ptr() + 2 * w_row_off * ktot
+        a.m, a.n, a.ktot, a.hw_out = m, nrows, ktot, hw_out
         a.bias = _ptr(bias)
         a.rowvec, a.rowvec_ld = rowvec, rowvec_ld
         a.resid, a.resid_ld, a.resid_rows = resid, resid_ld, resid_rows
