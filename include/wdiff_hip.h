@@ -34,7 +34,7 @@ extern "C" {
 
 #define WD_ACT_NONE 0
 #define WD_ACT_SILU 1
-#define WD_ACT_GEGLU 2 /* out[:, j] = x_j * gelu_erf(gate_j); weight rows interleaved in blocks of 32 */
+#define WD_ACT_GEGLU 2 /* out[:, j] = x_j * gelu_erf(gate_j); weight/bias rows packed per BN-tile as [BN/2 x | BN/2 gates]; tile must be set */
 
 typedef uint16_t wd_bf16;
 
@@ -82,6 +82,11 @@ typedef struct wd_gemm_args {
                            * (chunk-major, tap-minor) followed by the 32-channel chunks of src1: selects the kernel that
                            * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2) */
     int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192 */
+    int32_t ksplit;       /* 1: off.  >1: the K range is cut into ksplit slices run by separate workgroups (fills the chip
+                           * when m*n is small); partial sums go to ws and are combined in fixed order.  0: automatic
+                           * (splits only when ws is given and the tile grid would leave most CUs idle) */
+    float* ws;            /* split-K workspace (ksplit * m * n floats are used) or NULL */
+    int64_t ws_floats;    /* capacity of ws in floats */
     int32_t dbg;          /* must be 0; nonzero values switch parts of the kernel off for timing experiments (results invalid) */
 } wd_gemm_args;
 

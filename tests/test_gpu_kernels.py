@@ -38,7 +38,7 @@ SLAB = [False, True]
 
 
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None, slab=False):
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1):
     """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
     slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
@@ -79,6 +79,11 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
     if opl is not None:
         args.out_hi, args.out_lo, args.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), n_out
     args.tile = tile
+    args.ksplit = ksplit
+    if ksplit != 1:
+        ws = torch.empty(max(ksplit, 8) * m * n, device=DEV)
+        keep.append(ws)
+        args.ws, args.ws_floats = ws.data_ptr(), ws.numel()
     N.check(lib.wd_gemm(C.byref(args), _st()), "wd_gemm")
     torch.cuda.synchronize()
     return out, opl
@@ -164,17 +169,41 @@ def test_gemm_two_sources_film_residual_and_label_rows(slab):
 
 
 @pytest.mark.parametrize("slab", SLAB)
-def test_gemm_geglu_epilogue(slab):
-    g = torch.Generator().manual_seed(6)
-    m, dim, inner = 200, 64, 256
+@pytest.mark.parametrize("m,dim,inner,tile", [(200, 64, 256, 128064), (300, 320, 1280, 128160), (130, 64, 128, 64064)])
+def test_gemm_geglu_epilogue(slab, m, dim, inner, tile):
+    g = torch.Generator().manual_seed(6 + inner)
     a = torch.randn(m, dim, generator=g)
-    w = torch.randn(2 * inner, dim, generator=g) / 8
+    w = torch.randn(2 * inner, dim, generator=g) / dim ** 0.5
     b = torch.randn(2 * inner, generator=g)
     h = a.double() @ w.double().t() + b.double()
     ref = h[:, :inner] * F.gelu(h[:, inner:])
-    out, pl = run_gemm([(planes_of(a.to(DEV)), dim, 1, None, 0)], geglu_interleave(w).to(DEV), m, 1,
-                       bias=geglu_interleave(b).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=128064, slab=slab)
+    gr = (tile % 1000) // 2
+    out, pl = run_gemm([(planes_of(a.to(DEV)), dim, 1, None, 0)], geglu_interleave(w, gr).to(DEV), m, 1,
+                       bias=geglu_interleave(b, gr).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=tile, slab=slab)
     assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("ksplit", [0, 2, 5])
+def test_gemm_split_k(ksplit):
+    """K cut across workgroups + fixed-order reduce == the unsplit result (same epilogue), 3x3 + skip source included."""
+    g = torch.Generator().manual_seed(40 + ksplit)
+    B, hh, ww, c1, c2, n = 4, 4, 16, 320, 640, 320
+    hw, m = hh * ww, B * hh * ww
+    a1, a2 = torch.randn(m, c1, generator=g), torch.randn(m, c2, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    wcat = torch.randn(n, 9 * c1 + c2, generator=g) / 60
+    bias, film, res = torch.randn(n, generator=g), torch.randn(B, n, generator=g), torch.randn(m, n, generator=g)
+    x1 = a1.reshape(B, hh, ww, c1).permute(0, 3, 1, 2)
+    ref = (F.conv2d(x1.double(), wcat[:, :9 * c1].reshape(n, 3, 3, c1).permute(0, 3, 1, 2).double(), padding=1)
+           .permute(0, 2, 3, 1).reshape(m, n) + a2.double() @ wcat[:, 9 * c1:].double().t() + bias.double() +
+           film.double().repeat_interleave(hw, 0) + res.double())
+    srcs = [(planes_of(a1.to(DEV)), c1, 9, torch.from_numpy(tab).to(DEV), hw), (planes_of(a2.to(DEV)), c2, 1, None, 0)]
+    out, pl = run_gemm(srcs, wcat.to(DEV), m, hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV),
+                       want_planes=True, ksplit=ksplit)
+    assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
+    out2, _ = run_gemm(srcs, wcat.to(DEV), m, hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV),
+                       ksplit=ksplit)
+    assert torch.equal(out, out2)  # deterministic
 
 
 def test_gemm_rejects_bad_arguments():

@@ -72,7 +72,7 @@ def test_gather_tables_equal_torch_convs(h, w):
 
 def test_geglu_interleave_pairs_columns():
     w = torch.arange(2 * 64 * 3, dtype=torch.float32).reshape(128, 3)
-    p = geglu_interleave(w)
+    p = geglu_interleave(w, 32)
     for blk in range(2):
         assert torch.equal(p[64 * blk: 64 * blk + 32], w[32 * blk: 32 * blk + 32])
         assert torch.equal(p[64 * blk + 32: 64 * blk + 64], w[64 + 32 * blk: 64 + 32 * blk + 32])

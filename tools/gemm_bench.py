@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--slab", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--ksplit", type=int, default=1)
+    ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
+                    "2: same, then read the weights once (emulates a prefetch) before the launch")
     a = ap.parse_args()
     lib = N.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -70,22 +73,42 @@ def main():
         g.out_f32, g.out_ld = out.data_ptr(), n_out
         g.tile = a.tile if kind != "geglu" or a.tile else 0
         g.dbg = a.dbg
+        g.ksplit = a.ksplit
+        ws = torch.empty(8 * m * cout if a.ksplit != 1 and m * cout * 8 < 2 ** 28 else 1, device=DEV)
+        if a.ksplit != 1:
+            g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
         if a.slab:
             g.w_layout, g.slab_rows = 1, slab_span(tab_np, hw, hw, m)
-            if kind == "geglu" and not g.tile:
-                g.tile = 128064
+        if kind == "geglu" and not g.tile:
+            g.tile = 128160
         for _ in range(3):
             N.check(lib.wd_gemm(C.byref(g), st), name)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            lib.wd_gemm(C.byref(g), st)
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / a.iters
+        if a.cold:
+            junk = torch.empty(256 * 1024 * 1024, device=DEV)
+            tot = 0.0
+            for _ in range(a.iters):
+                junk.fill_(1.0)
+                if a.cold == 2:
+                    wt.sum()
+                if a.cold == 3:
+                    wt.sum(); act.sum()
+                e0.record()
+                lib.wd_gemm(C.byref(g), st)
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            us = 1e3 * tot / a.iters
+        else:
+            e0.record()
+            for _ in range(a.iters):
+                lib.wd_gemm(C.byref(g), st)
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / a.iters
         fl = 2.0 * m * cout * ktot
-        print(f"{name:12s} m={m:6d} n={cout:5d} k={ktot:5d} tile={a.tile:6d} npass={a.npass} slab={a.slab} dbg={a.dbg}: {us:8.1f} us  "
+        print(f"{name:12s} m={m:6d} n={cout:5d} k={ktot:5d} tile={a.tile:6d} npass={a.npass} slab={a.slab} ksplit={a.ksplit} cold={a.cold}: {us:8.1f} us  "
               f"{fl / us / 1e6:7.1f} TF/s algorithmic ({a.npass * fl / us / 1e6:7.1f} MFMA)", flush=True)
 
 

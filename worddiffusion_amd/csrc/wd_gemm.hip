@@ -26,63 +26,138 @@ constexpr int BK = 32;
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` inside a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
 
-// ---- epilogue shared by all kernels.  C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-// All global reads of a column tile (bias once, FiLM row vector and residual for its 16 rows) are issued together
-// before the first use, so the tail costs a handful of memory round trips instead of one per output element.
-template <int TN>
-__device__ __forceinline__ void wd_epilogue(const wd_gemm_args& a, const f32x16 (&acc)[TN], const int mrow0,
-                                            const int ncolbase, const int lane) {
+// ---- vectorised epilogue shared by all kernels: the accumulators of all waves go through an fp32 LDS image of
+// the output tile (which also sums the two k-halves of the 8-wave variants), then every thread reads float4s
+// row-major and does bias / FiLM / residual / activation with 16-byte global loads and stores.
+template <int BM, int BN, int TN, int NT>
+__device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32x16 (&acc)[TN], char* smem, const int m0,
+                                                const int n0, const int wm, const int wn, const int wcols, const int kh,
+                                                const int nkh, const int tid, const int sidx = 0) {
+    constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
+    float* ep = reinterpret_cast<float*>(smem);
+    const int lane = tid & 63;
     const int frow = lane & 31, fhalf = lane >> 5;
-    const int ncol0 = ncolbase + frow;
-    const bool geglu = a.act == WD_ACT_GEGLU;
-    long rv_off[16], rs_off[16];
-    bool mok[16];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with the operand buffers
+    for (int h = 0; h < nkh; ++h) {
+        if (kh == h) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        mok[r] = m < a.m;
-        const int mm = mok[r] ? m : 0;
-        rv_off[r] = a.rowvec ? (long)(mm / a.hw_out) * a.rowvec_ld : 0;
-        rs_off[r] = a.resid ? (a.resid_rows ? (long)a.resid_rows[mm] : (long)mm) * a.resid_ld : 0;
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* p = ep + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * LDE + wn * wcols + t * 32 + frow;
+                    *p = (h == 0) ? acc[t][r] : *p + acc[t][r];
+                }
+        }
+        __syncthreads();
     }
-    constexpr int TSTEP = 1;
-#pragma unroll
-    for (int t = 0; t < TN; t += TSTEP) {
-        if (geglu && (t & 1)) continue;  // gate tiles are consumed together with their x tile
-        const int nx = ncol0 + t * 32;            // column in the accumulator / bias index space
-        const int ng = nx + 32;                   // GEGLU gate column
-        const int no = geglu ? (ncolbase >> 1) + (t >> 1) * 32 + frow : nx;  // output column
-        const bool nok = geglu ? (ng < a.n) : (nx < a.n);
-        float bx = 0.f, bg = 0.f;
-        if (a.bias && nok) {
-            bx = a.bias[nx];
-            if (geglu) bg = a.bias[ng];
+    if (a.ksplit > 1) {  // raw partial sums of this K slice -> ws[sidx][m][n]; wd_gemm_reduce applies the epilogue
+        float* ws = a.ws + (long)sidx * a.m * a.n;
+        const bool v4 = (a.n & 3) == 0;
+        for (int i = tid; i < BM * (BN / 4); i += NT) {
+            const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + c;
+            if (m >= a.m || n >= a.n) continue;
+            const float4 v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+            if (v4) {
+                *reinterpret_cast<float4*>(ws + (long)m * a.n + n) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < 4 && n + j < a.n; ++j) ws[(long)m * a.n + n + j] = e[j];
+            }
         }
-        float rvv[16], rsv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            rvv[r] = (a.rowvec && nok && mok[r]) ? a.rowvec[rv_off[r] + no] : 0.f;
-            rsv[r] = (a.resid && nok && mok[r]) ? a.resid[rs_off[r] + no] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (!(nok && mok[r])) continue;
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        return;
+    }
+    const bool geglu = a.act == WD_ACT_GEGLU;
+    const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
+    const int oc4 = ocols / 4;
+    const int nout = geglu ? a.n / 2 : a.n;
+    const int no0 = geglu ? n0 / 2 : n0;
+    // 16-byte path needs aligned rows everywhere; otherwise (odd leading dimensions) one element at a time
+    const bool vec = (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
+                        reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32)) & 15) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0);
+    if (!vec) {
+        for (int i = tid; i < BM * ocols; i += NT) {
+            const int row = i / ocols, c = i - row * ocols;
+            const int m = m0 + row, no = no0 + c;
+            if (m >= a.m || no >= nout) continue;
             float v;
             if (geglu) {
-                const float x = acc[t][r] + bx;
-                const float g = acc[(t + 1 < TN) ? t + 1 : t][r] + bg;
-                v = x * wd_gelu_erf(g) + rvv[r] + rsv[r];
+                const float x = ep[row * LDE + c] + (a.bias ? a.bias[n0 + c] : 0.f);
+                const float g = ep[row * LDE + c + BN / 2] + (a.bias ? a.bias[n0 + c + BN / 2] : 0.f);
+                v = x * wd_gelu_erf(g);
             } else {
-                v = acc[t][r] + bx + rvv[r] + rsv[r];
-                if (a.act == WD_ACT_SILU) v = wd_silu(v);
+                v = ep[row * LDE + c] + (a.bias ? a.bias[no] : 0.f);
             }
+            if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
+            if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
+            if (a.act == WD_ACT_SILU) v = wd_silu(v);
             if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
             if (a.out_hi) {
-                uint32_t h, l;
-                wd_split1(v, h, l);
-                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)h;
-                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)l;
+                uint32_t hb, lb;
+                wd_split1(v, hb, lb);
+                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
+                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)lb;
+            }
+        }
+        return;
+    }
+    for (int i = tid; i < BM * oc4; i += NT) {
+        const int row = i / oc4, c = (i - row * oc4) * 4;
+        const int m = m0 + row, no = no0 + c;
+        if (m >= a.m || no >= nout) continue;
+        float4 v;
+        if (geglu) {  // columns [0, BN/2) of the tile are x, [BN/2, BN) their gates (weights packed that way)
+            const float4 x = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+            const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + c + BN / 2);
+            float4 bx = make_float4(0, 0, 0, 0), bg = bx;
+            if (a.bias) {
+                bx = *reinterpret_cast<const float4*>(a.bias + n0 + c);
+                bg = *reinterpret_cast<const float4*>(a.bias + n0 + c + BN / 2);
+            }
+            v.x = (x.x + bx.x) * wd_gelu_erf(g.x + bg.x);
+            v.y = (x.y + bx.y) * wd_gelu_erf(g.y + bg.y);
+            v.z = (x.z + bx.z) * wd_gelu_erf(g.z + bg.z);
+            v.w = (x.w + bx.w) * wd_gelu_erf(g.w + bg.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + no);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+        }
+        if (a.rowvec) {
+            const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (a.resid) {
+            const long rr = a.resid_rows ? (long)a.resid_rows[m] : (long)m;
+            const float4 q = *reinterpret_cast<const float4*>(a.resid + rr * a.resid_ld + no);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (a.act == WD_ACT_SILU) {
+            v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
+        }
+        if (no + 3 < nout) {
+            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
+            if (a.out_hi) {
+                uint2 hh, ll;
+                wd_split4(v, hh, ll);
+                *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
+                if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + no) = ll;
+            }
+        } else {  // ragged right edge (n not a multiple of 4 columns inside this float4)
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4 && no + j < nout; ++j) {
+                if (a.out_f32) a.out_f32[(long)m * a.out_ld + no + j] = e[j];
+                if (a.out_hi) {
+                    uint32_t hb, lb;
+                    wd_split1(e[j], hb, lb);
+                    a.out_hi[(long)m * a.out_pl_ld + no + j] = (wd_bf16)hb;
+                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no + j] = (wd_bf16)lb;
+                }
             }
         }
     }
@@ -263,129 +338,7 @@ __global__ void __launch_bounds__(256, 2) wd_gemm_kernel(const wd_gemm_args a, c
         __syncthreads();
     }
 
-    wd_epilogue<TN>(a, acc, m0 + wm * 32, n0 + wn * WCOLS, lane);
-}
-
-// ---- vectorised epilogue for the v2 / v3 kernels: the accumulators of all waves go through an fp32 LDS image of
-// the output tile (which also sums the two k-halves of the 8-wave variants), then every thread reads float4s
-// row-major and does bias / FiLM / residual / activation with 16-byte global loads and stores.
-template <int BM, int BN, int TN, int NT>
-__device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32x16 (&acc)[TN], char* smem, const int m0,
-                                                const int n0, const int wm, const int wn, const int wcols, const int kh,
-                                                const int nkh, const int tid) {
-    constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
-    float* ep = reinterpret_cast<float*>(smem);
-    const int lane = tid & 63;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave is done with the operand buffers
-    for (int h = 0; h < nkh; ++h) {
-        if (kh == h) {
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* p = ep + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * LDE + wn * wcols + t * 32 + frow;
-                    *p = (h == 0) ? acc[t][r] : *p + acc[t][r];
-                }
-        }
-        __syncthreads();
-    }
-    const bool geglu = a.act == WD_ACT_GEGLU;
-    const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
-    const int oc4 = ocols / 4;
-    const int nout = geglu ? a.n / 2 : a.n;
-    const int no0 = geglu ? n0 / 2 : n0;
-    // 16-byte path needs aligned rows everywhere; otherwise (odd leading dimensions) one element at a time
-    const bool vec = (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
-                     (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
-                        reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32)) & 15) == 0) &&
-                     (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0);
-    if (!vec) {
-        for (int i = tid; i < BM * ocols; i += NT) {
-            const int row = i / ocols, c = i - row * ocols;
-            const int m = m0 + row, no = no0 + c;
-            if (m >= a.m || no >= nout) continue;
-            float v;
-            if (geglu) {
-                const int ec = (c >> 5) * 64 + (c & 31);
-                const float x = ep[row * LDE + ec] + (a.bias ? a.bias[n0 + ec] : 0.f);
-                const float g = ep[row * LDE + ec + 32] + (a.bias ? a.bias[n0 + ec + 32] : 0.f);
-                v = x * wd_gelu_erf(g);
-            } else {
-                v = ep[row * LDE + c] + (a.bias ? a.bias[no] : 0.f);
-            }
-            if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
-            if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
-            if (a.act == WD_ACT_SILU) v = wd_silu(v);
-            if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
-            if (a.out_hi) {
-                uint32_t hb, lb;
-                wd_split1(v, hb, lb);
-                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
-                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)lb;
-            }
-        }
-        return;
-    }
-    for (int i = tid; i < BM * oc4; i += NT) {
-        const int row = i / oc4, c = (i - row * oc4) * 4;
-        const int m = m0 + row, no = no0 + c;
-        if (m >= a.m || no >= nout) continue;
-        float4 v;
-        if (geglu) {
-            const int ec = (c >> 5) * 64 + (c & 31);
-            const float4 x = *reinterpret_cast<const float4*>(ep + row * LDE + ec);
-            const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + ec + 32);
-            float4 bx = make_float4(0, 0, 0, 0), bg = bx;
-            if (a.bias) {
-                bx = *reinterpret_cast<const float4*>(a.bias + n0 + ec);
-                bg = *reinterpret_cast<const float4*>(a.bias + n0 + ec + 32);
-            }
-            v.x = (x.x + bx.x) * wd_gelu_erf(g.x + bg.x);
-            v.y = (x.y + bx.y) * wd_gelu_erf(g.y + bg.y);
-            v.z = (x.z + bx.z) * wd_gelu_erf(g.z + bg.z);
-            v.w = (x.w + bx.w) * wd_gelu_erf(g.w + bg.w);
-        } else {
-            v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + no);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            }
-        }
-        if (a.rowvec) {
-            const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (a.resid) {
-            const long rr = a.resid_rows ? (long)a.resid_rows[m] : (long)m;
-            const float4 q = *reinterpret_cast<const float4*>(a.resid + rr * a.resid_ld + no);
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (a.act == WD_ACT_SILU) {
-            v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
-        }
-        if (no + 3 < nout) {
-            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
-            if (a.out_hi) {
-                uint2 hh, ll;
-                wd_split4(v, hh, ll);
-                *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
-                if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + no) = ll;
-            }
-        } else {  // ragged right edge (n not a multiple of 4 columns inside this float4)
-            const float e[4] = {v.x, v.y, v.z, v.w};
-            for (int j = 0; j < 4 && no + j < nout; ++j) {
-                if (a.out_f32) a.out_f32[(long)m * a.out_ld + no + j] = e[j];
-                if (a.out_hi) {
-                    uint32_t hb, lb;
-                    wd_split1(e[j], hb, lb);
-                    a.out_hi[(long)m * a.out_pl_ld + no + j] = (wd_bf16)hb;
-                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no + j] = (wd_bf16)lb;
-                }
-            }
-        }
-    }
+    wd_epilogue_lds<BM, BN, TN, 256>(a, acc, smem, m0, n0, wm, wn, WCOLS, 0, 1, tid);
 }
 
 // ======================================================================================================
@@ -425,13 +378,17 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE);  // [ntaps0][BM] source row of src[0] per tap, -1 = zero row
 
-    const int nwg = nbn * nbm;
+    const int ntile = nbn * nbm;
+    const int nwg = ntile * a.ksplit;
     int wg;
     {
         const int bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    // split-K across workgroups: slice `sidx` of the K stages of tile `wg % ntile` (partials summed by wd_gemm_reduce)
+    const int sidx = wg / ntile;
+    wg -= sidx * ntile;
     const int bn_i = wg % nbn, bm_i = wg / nbn;
     const int m0 = bm_i * BM, n0 = bn_i * BN;
 
@@ -483,10 +440,27 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
     }
     const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
 
+    const int nk_all = a.ktot / BK2;
+    const int k_begin = (int)((long)nk_all * sidx / a.ksplit), k_end = (int)((long)nk_all * (sidx + 1) / a.ksplit);
     int s = 0, tap = 0, kc = 0;
     const wd_bf16* cur_hi = a.src[0].hi;
     const wd_bf16* cur_lo = a.src[0].lo;
     int cur_ld = a.src[0].ld, cur_c = a.src[0].c, cur_nt = a.src[0].ntaps;
+    {   // (source, tap, chunk) of the first stage of this slice
+        const int cpt = a.src[0].c / BK2, n0st = a.src[0].ntaps * cpt;
+        if (k_begin < n0st) {
+            tap = k_begin / cpt;
+            kc = k_begin - tap * cpt;
+        } else {
+            s = 1;
+            kc = k_begin - n0st;
+            cur_hi = a.src[1].hi;
+            cur_lo = a.src[1].lo;
+            cur_ld = a.src[1].ld;
+            cur_c = a.src[1].c;
+            cur_nt = a.src[1].ntaps;
+        }
+    }
     long a_off[A_INS];
 
     auto locate = [&]() {
@@ -503,33 +477,37 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
     };
     locate();
 
-    auto issue = [&](int kit, int stage) {
-        char* sbase = smem + stage * STAGE;
+    // One stage = NSLOT DMA pieces for this wave (A hi/lo pieces first, then W hi/lo).  The addresses of the next stage
+    // are computed up front (prep), the global_load_lds themselves are issued one by one BETWEEN the MFMA groups of the
+    // current stage (fire), so that DMA issue hides in the MFMA pipe's shadow instead of preceding it as a burst.
+    constexpr int NSLOT = NPL * (A_INS + B_INS);
+    const wd_bf16* pp[NSLOT];   // per-lane source pointer of each piece (zero line for padding / out-of-range rows)
+    int pdst[NSLOT];            // wave-uniform LDS byte offset inside the stage, < 0: this wave has no such piece
+    auto prep = [&](int kit) {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
-            const int piece = wave + NW * i;  // wave-uniform
-            if (piece < A_PIECES) {
-                const wd_bf16* ph = a_off[i] >= 0 ? cur_hi + a_off[i] + kc * BK2 : zline;
-                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(sbase + piece * 1024), 16, 0, 0);
-                if (NPL == 2) {
-                    const wd_bf16* pl = a_off[i] >= 0 ? cur_lo + a_off[i] + kc * BK2 : zline;
-                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(sbase + A_PL + piece * 1024), 16, 0, 0);
-                }
+            const int piece = wave + NW * i;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const int sl = i * NPL + p;
+                pdst[sl] = piece < A_PIECES ? p * A_PL + piece * 1024 : -1;
+                pp[sl] = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK2 : zline;
             }
         }
-        char* bb = sbase + NPL * A_PL;
 #pragma unroll
         for (int i = 0; i < B_INS; ++i) {
             const int piece = wave + NW * i;
-            if (piece < B_PIECES) {
-                const wd_bf16* ph = b_ok[i] ? a.w_hi + b_off[i] + (long)kit * BK2 : zline;
-                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)ph, (wd_lds_ptr)(bb + piece * 1024), 16, 0, 0);
-                if (NPL == 2) {
-                    const wd_bf16* pl = b_ok[i] ? a.w_lo + b_off[i] + (long)kit * BK2 : zline;
-                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pl, (wd_lds_ptr)(bb + B_PL + piece * 1024), 16, 0, 0);
-                }
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const int sl = A_INS * NPL + i * NPL + p;
+                pdst[sl] = piece < B_PIECES ? NPL * A_PL + p * B_PL + piece * 1024 : -1;
+                pp[sl] = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK2 : zline;
             }
         }
+    };
+    auto fire = [&](int sl, char* sbase) {
+        if (pdst[sl] >= 0)
+            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pp[sl], (wd_lds_ptr)(sbase + pdst[sl]), 16, 0, 0);
     };
     auto advance = [&]() {
         ++kc;
@@ -557,41 +535,58 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    const int nk = a.ktot / BK2;
-    issue(0, 0);
-    advance();
+    const int nk = k_end - k_begin;
+    if (nk > 0) {
+        prep(k_begin);
+        advance();
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) fire(sl, smem);
+    }
 
     const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int NGRP = KK_PER * TN;  // MFMA groups (one 32x32 tile x one 16-deep k-step) of this wave per stage
     for (int kit = 0; kit < nk; ++kit) {
-        __syncthreads();  // vmcnt(0) + barrier: step kit has landed, everybody is done reading the other stage
-        if (kit + 1 < nk) {
-            issue(kit + 1, (kit + 1) & 1);
+        __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+        const bool more = kit + 1 < nk;
+        if (more) {
+            prep(k_begin + kit + 1);
             advance();
         }
         const char* base = smem + (kit & 1) * STAGE;
+        char* nbase = smem + ((kit + 1) & 1) * STAGE;
+        bf16x8 fa[KK_PER][NPL], fb[KK_PER][TN][NPL];
 #pragma unroll
         for (int k2 = 0; k2 < KK_PER; ++k2) {
-            const int kk = kh * KK_PER + k2;
-            const int ch = kk * 2 + fhalf;
+            const int ch = (kh * KK_PER + k2) * 2 + fhalf;
             const int ao = lds_off2(wm * 32 + frow, ch);
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + ao);
-            bf16x8 al;
-            if (NPL == 2) al = *reinterpret_cast<const bf16x8*>(base + A_PL + ao);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) fa[k2][p] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + ao);
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 const int bo = NPL * A_PL + lds_off2(wn * WCOLS + t * 32 + frow, ch);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(base + bo);
-                if (NPL == 2) {
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(base + B_PL + bo);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) fb[k2][t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            const int k2 = g / TN, t = g % TN;
+            if (NPL == 2) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][NPL - 1], fb[k2][t][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][0], fb[k2][t][NPL - 1], acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][0], fb[k2][t][0], acc[t], 0, 0, 0);
+            // spread this wave's DMA pieces of the next stage over the MFMA groups
+            if (more) {
+#pragma unroll
+                for (int sl = g * NSLOT / NGRP; sl < (g + 1) * NSLOT / NGRP; ++sl) fire(sl, nbase);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    wd_epilogue_lds<BM, BN, TN, 256 * KS>(a, acc, smem, m0, n0, wm, wn, WCOLS, kh, KS, tid);
+    wd_epilogue_lds<BM, BN, TN, 256 * KS>(a, acc, smem, m0, n0, wm, wn, WCOLS, kh, KS, tid, sidx);
 }
 
 // ======================================================================================================
@@ -897,7 +892,9 @@ int launch3(const wd_gemm_args& a, hipStream_t st) {
 template <int BM, int BN, int NPASS>
 int launch(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
-    constexpr int smem = 2 * NPL * (BM + BN) * 64;
+    constexpr int loop_smem = 2 * NPL * (BM + BN) * 64;
+    constexpr int red_smem = BM * (BN + 4) * 4;
+    constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;  // one process = one device, set once per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm_kernel<BM, BN, NPASS>),
@@ -909,6 +906,28 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
     WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
     hipLaunchKernelGGL((wd_gemm_kernel<BM, BN, NPASS>), dim3(nbn * nbm), dim3(256), smem, st, a, nbn, nbm);
     return wd_check_launch();
+}
+
+// out = epilogue(sum of the ksplit partial slabs) - the same bias / FiLM / residual / activation / plane outputs as the
+// in-kernel epilogue, in a fixed summation order (deterministic).
+__global__ void wd_gemm_reduce_kernel(const wd_gemm_args a) {
+    const long total = (long)a.m * a.n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / a.n), n = (int)(i - (long)m * a.n);
+        float v = 0.f;
+        for (int sp = 0; sp < a.ksplit; ++sp) v += a.ws[(long)sp * total + i];
+        if (a.bias) v += a.bias[n];
+        if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + n];
+        if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + n];
+        if (a.act == WD_ACT_SILU) v = wd_silu(v);
+        if (a.out_f32) a.out_f32[(long)m * a.out_ld + n] = v;
+        if (a.out_hi) {
+            uint32_t hb, lb;
+            wd_split1(v, hb, lb);
+            a.out_hi[(long)m * a.out_pl_ld + n] = (wd_bf16)hb;
+            if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + n] = (wd_bf16)lb;
+        }
+    }
 }
 
 template <int BM, int BN, int NPASS, int KS>
@@ -926,7 +945,13 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
     WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS>), dim3(nbn * nbm), dim3(256 * KS), smem, st, a, nbn, nbm);
+    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
+                       nbn, nbm);
+    if (a.ksplit > 1) {
+        const long total = (long)a.m * a.n;
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(wd_gemm_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
+    }
     return wd_check_launch();
 }
 
@@ -934,7 +959,10 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
 
 extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
-    const wd_gemm_args& a = *pa;
+    wd_gemm_args a = *pa;
+    if (a.ksplit < 0 || a.ksplit > 16) return WD_EINVAL;
+    if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout != 0)) return WD_EINVAL;
+    if (a.w_layout != 0) a.ksplit = 1;
     if (a.nsrc < 1 || a.nsrc > 2 || (a.npass != 1 && a.npass != 3)) return WD_EINVAL;
     if (a.m <= 0 || a.n <= 0 || a.hw_out <= 0 || !a.w_hi || (a.npass == 3 && !a.w_lo)) return WD_EINVAL;
     if (!a.out_f32 && !a.out_hi) return WD_EINVAL;
@@ -948,7 +976,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         k += (long)q.ntaps * q.c;
     }
     if (k != a.ktot) return WD_EINVAL;
-    if (a.act == WD_ACT_GEGLU && (a.n % 64)) return WD_EINVAL;
+    if (a.act == WD_ACT_GEGLU && (a.n % 64 || a.tile == 0)) return WD_EINVAL;  // the tile fixes the x|gate packing
     if (a.rowvec && a.rowvec_ld <= 0) return WD_EINVAL;
     if (a.resid && a.resid_ld <= 0) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -959,7 +987,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (a.nsrc == 2 && (a.src[1].gather || a.src[1].ntaps != 1)) return WD_EINVAL;
         int t3 = a.tile;
         if (t3 == 0) t3 = (a.act == WD_ACT_GEGLU || a.n % 160) ? 128064 : 128160;
-        if (a.act == WD_ACT_GEGLU && t3 != 128064 && t3 != 128128) return WD_EINVAL;
+        if (a.act == WD_ACT_GEGLU && a.n % (t3 % 1000)) return WD_EINVAL;
         if (a.slab_rows > 192) return WD_EINVAL;
         static const int ks3_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
 #define WD_DISPATCH3(BM_, BN_)                                                                                   \
@@ -973,24 +1001,40 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         }
 #undef WD_DISPATCH3
     }
-    int tile = a.tile;
-    if (tile == 0) {
-        // heuristics: keep >= ~1 workgroup per CU; GEGLU pairs column tiles inside one wave (needs 128x64 / 64x64 ...)
-        const long big = (long)((a.m + 127) / 128) * ((a.n + 159) / 160);
-        if (a.act == WD_ACT_GEGLU) tile = ((long)((a.m + 127) / 128) * (a.n / 64) >= 192) ? 128064 : 128064;
-        else if (a.n % 160 == 0 && big >= 192) tile = 128160;
-        else if ((long)((a.m + 127) / 128) * ((a.n + 63) / 64) >= 192) tile = 128064;
-        else tile = (a.m > 64 * 2) ? 64064 : 128064;
-    }
-    if (a.act == WD_ACT_GEGLU && tile != 128064 && tile != 128128) return WD_EINVAL;
     bool v2ok = (a.ktot % BK2 == 0) && !getenv("WDIFF_GEMM_V1");
-    static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
-    const int ks = ks_env == 1 ? 1 : 2;
     for (int s = 0; s < a.nsrc; ++s) v2ok = v2ok && (a.src[s].c % BK2 == 0);
     v2ok = v2ok && a.src[0].ntaps <= 9 && (a.nsrc == 1 || (a.src[1].gather == nullptr && a.src[1].ntaps == 1));
+    const int nk64 = a.ktot / BK2;
+    int tile = a.tile;
+    if (tile == 0) {
+        // 128x160 when N allows it (A is re-read only N/160 times), else 128x64; when that leaves most CUs idle either
+        // cut K across workgroups (needs a workspace and enough K per slice) or fall back to 64x64 tiles.
+        tile = (a.n % 160 == 0) ? 128160 : 128064;
+        const long tiles = (long)((a.m + 127) / 128) * ((a.n + (tile % 1000) - 1) / (tile % 1000));
+        const bool can_split = v2ok && a.ws && a.ksplit == 0 && a.act != WD_ACT_GEGLU && nk64 >= 8 &&
+                               (long)2 * a.m * a.n <= a.ws_floats;
+        if (tiles < 128 && !can_split && a.m > 64) tile = 64064;
+    }
+    if (a.ksplit == 0) {
+        a.ksplit = 1;
+        const int bn = tile % 1000, bm = tile / 1000;
+        const long tiles = (long)((a.m + bm - 1) / bm) * ((a.n + bn - 1) / bn);
+        if (v2ok && a.ws && a.act != WD_ACT_GEGLU && tiles < 128 && nk64 >= 8) {
+            long sp = 256 / tiles;
+            if (sp > nk64 / 4) sp = nk64 / 4;
+            if (sp > 8) sp = 8;
+            while (sp > 1 && sp * a.m * a.n > a.ws_floats) --sp;
+            if (sp > 1) a.ksplit = (int)sp;
+        }
+    }
+    if (a.act == WD_ACT_GEGLU && a.n % (tile % 1000)) return WD_EINVAL;
+    if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
+    static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
+    const int ks = ks_env == 1 ? 1 : 2;
 #define WD_DISPATCH(BM_, BN_)                                                                      \
     if (v2ok && ks == 2) return a.npass == 3 ? launch2<BM_, BN_, 3, 2>(a, st) : launch2<BM_, BN_, 1, 2>(a, st); \
     if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3, 1>(a, st) : launch2<BM_, BN_, 1, 1>(a, st); \
+    a.ksplit = 1;                                                                                   \
     return a.npass == 3 ? launch<BM_, BN_, 3>(a, st) : launch<BM_, BN_, 1>(a, st)
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);

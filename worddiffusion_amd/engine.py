@@ -61,14 +61,19 @@ def conv_gather_table(h: int, w: int, mode: str) -> Tuple[np.ndarray, int, int]:
     return tab, ho, wo
 
 
-def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
-    """Rows [x | gate] (unet.py:128 ``chunk(2)``) -> blocks of 32 x-rows followed by their 32 gate rows, so
-    that one wave of ``wd_gemm`` holds both halves of an output column in the same lane."""
+def geglu_interleave(w: torch.Tensor, g: int = 32) -> torch.Tensor:
+    """Rows [x | gate] (unet.py:128 ``chunk(2)``) -> blocks of ``g`` x-rows followed by their ``g`` gate rows, so
+    that one BN = 2g column tile of ``wd_gemm`` holds both halves of ``g`` output columns."""
     inner = w.shape[0] // 2
-    assert inner % 32 == 0
-    x = w[:inner].reshape(inner // 32, 32, *w.shape[1:])
-    g = w[inner:].reshape(inner // 32, 32, *w.shape[1:])
-    return torch.stack([x, g], dim=1).reshape(w.shape)
+    assert inner % g == 0
+    x = w[:inner].reshape(inner // g, g, *w.shape[1:])
+    gt = w[inner:].reshape(inner // g, g, *w.shape[1:])
+    return torch.stack([x, gt], dim=1).reshape(w.shape)
+
+
+def geglu_tile(inner: int) -> int:
+    """GEMM tile for a GEGLU projection with ``inner`` output columns: 128x160 when 80 divides it."""
+    return 128160 if inner % 80 == 0 else 128064
 
 
 def slab_order(wp: torch.Tensor, ntaps0: int, c0: int, c1: int = 0) -> torch.Tensor:
@@ -153,6 +158,7 @@ class UNetEngine:
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
+        self._ws = None
         self.device = None
 
     # ------------------------------------------------------------------------------------------ weights
@@ -255,8 +261,10 @@ class UNetEngine:
                     for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
                         rec[f"{p}.{tag}.o.w"] = (lambda at=at: at.to_out[0].weight)
                         rec[f"{p}.{tag}.o.b"] = (lambda at=at: at.to_out[0].bias)
-                    rec[p + ".ff1.w"] = (lambda tb=tb: geglu_interleave(tb.ff.net[0].proj.weight))
-                    rec[p + ".ff1.b"] = (lambda tb=tb: geglu_interleave(tb.ff.net[0].proj.bias))
+                    rec[p + ".ff1.w"] = (lambda tb=tb: geglu_interleave(
+                        tb.ff.net[0].proj.weight, geglu_tile(tb.ff.net[2].in_features) % 1000 // 2))
+                    rec[p + ".ff1.b"] = (lambda tb=tb: geglu_interleave(
+                        tb.ff.net[0].proj.bias, geglu_tile(tb.ff.net[2].in_features) % 1000 // 2))
                     rec[p + ".ff2.w"] = (lambda tb=tb: tb.ff.net[2].weight)
                     rec[p + ".ff2.b"] = (lambda tb=tb: tb.ff.net[2].bias)
         self.film_total = off
@@ -300,6 +308,7 @@ class UNetEngine:
             self._plans.clear()
             self._tabs.clear()
             self._tab_np.clear()
+            self._ws = None
         self.device = dev
         with torch.no_grad():
             for name, fn in self._recipes().items():
@@ -398,6 +407,9 @@ class UNetEngine:
         if out_pl is not None:
             a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), out_pl[1].data_ptr(), out_pl.shape[2]
         a.tile = tile
+        if self._ws is None:
+            self._ws = torch.empty(128 * 128 * 160 * 8, dtype=torch.float32, device=self.device)  # 84 MB split-K scratch
+        a.ksplit, a.ws, a.ws_floats = 0, self._ws.data_ptr(), self._ws.numel()
         self._cur_plan.keep.append(a)
         ops.append((self.lib.wd_gemm, (C.byref(a),), what))
         return a
@@ -546,7 +558,7 @@ class UNetEngine:
             n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
             ffh = self._planes(P, M, 4 * inner)
             self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1.w", M, hw, bias=self._w[p + ".ff1.b"],
-                       act=N.ACT_GEGLU, out_pl=ffh, tile=128064)
+                       act=N.ACT_GEGLU, out_pl=ffh, tile=geglu_tile(4 * inner))
             last = di == len(mod.transformer_blocks) - 1
             tok = self._f32(P, M, inner)
             xpl = self._planes(P, M, inner) if last else None
