@@ -87,20 +87,28 @@ typedef struct wd_gemm_args {
                            * (splits only when ws is given and the tile grid would leave most CUs idle) */
     float* ws;            /* split-K workspace (ksplit * m * n floats are used) or NULL */
     int64_t ws_floats;    /* capacity of ws in floats */
+    double* stat_part;    /* NULL, or [m / hw_out][nchunk][n / stat_cpg][2] (sum, sum of squares) of the finished output per
+                           * (sample, 128-row chunk, channel group): GroupNorm statistics for the consumer (wd_gn_apply),
+                           * nchunk = max(1, hw_out / 128).  Needs 128-row tiles, hw_out | 128 or 128 | hw_out, whole
+                           * groups per column tile; not with GEGLU */
+    int32_t stat_cpg;     /* channels per statistics group */
     int32_t dbg;          /* must be 0; nonzero values switch parts of the kernel off for timing experiments (results invalid) */
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);
 
-/* GroupNorm(32 groups) statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).
- * x: [B*hw][ld] fp32, channels [0, c) hold groups [g0, g0 + c/cpg).  Writes per (sample, chunk, group)
- * partial (sum, sumsq) in double into part[(b*nchunk + j)*32 + g]; nchunk = wd_gn_nchunk(hw). */
+/* GroupNorm statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).  x: [B*hw][ld] fp32 with c channels in
+ * groups of cpg.  Writes per (sample, chunk, group) partial (sum, sumsq) in double: part[((b*nchunk + j)*(c/cpg) + g)*2],
+ * nchunk = wd_gn_nchunk(hw).  (wd_gemm can produce the same array in its epilogue: wd_gemm_args.stat_part.) */
 int wd_gn_nchunk(int hw);
-int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, double* part, void* stream);
+int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, double* part, void* stream);
 
-/* Normalise (+ optional SiLU) and emit split-bf16 planes: out[m][c_off + ch] for ch in [0, c).
- * Also (raw_hi != NULL) the un-normalised input as planes for a 1x1 skip convolution (unet.py:632,671). */
-int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, const double* part,
+/* Normalise (+ optional SiLU) channels [0, c) of x with groups of cpg channels and emit split-bf16 planes
+ * out[m][c_off + ch].  `part` holds nchunk partials per sample at a granularity of part_cpg channels (part_cpg | cpg: a
+ * 320-channel tensor keeps 10-channel partials that also serve the 20-channel groups of a 640-channel concat norm).
+ * gamma/beta are the norm's full affine vectors (indexed at c_off + ch).  raw_hi != NULL: also the un-normalised input
+ * as planes for a 1x1 skip convolution (unet.py:632,671). */
+int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, const double* part, int nchunk, int part_cpg,
                 const float* gamma, const float* beta, float eps, int silu,
                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int c_off,
                 wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);

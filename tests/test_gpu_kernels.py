@@ -230,25 +230,87 @@ def test_groupnorm_silu_planes(B, hw, cs, silu, eps):
     if any(c % cpg for c in cs):
         pytest.skip("straddling groups are materialised by the engine (wd_copy2d)")
     nchunk = lib.wd_gn_nchunk(hw)
-    part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
     pl = torch.zeros(2, B * hw, ctot, dtype=torch.bfloat16, device=DEV)
     raw = torch.zeros_like(pl)
     xd = [x.to(DEV) for x in xs]
     gd, bd = gamma.to(DEV), beta.to(DEV)
-    g0 = 0
-    for x, c in zip(xd, cs):
-        N.check(lib.wd_gn_stats(x.data_ptr(), c, B, hw, c, cpg, g0, part.data_ptr(), _st()), "stats")
-        g0 += c // cpg
-    g0 = off = 0
-    for x, c in zip(xd, cs):
-        N.check(lib.wd_gn_apply(x.data_ptr(), c, B, hw, c, cpg, g0, part.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps,
-                                silu, pl[0].data_ptr(), pl[1].data_ptr(), ctot, off, raw[0].data_ptr(),
-                                raw[1].data_ptr(), _st()), "apply")
-        g0 += c // cpg
+    parts = []
+    for x, c in zip(xd, cs):  # every tensor keeps its own 32-group partials (c/32 channels each)
+        part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+        N.check(lib.wd_gn_stats(x.data_ptr(), c, B, hw, c, c // 32, part.data_ptr(), _st()), "stats")
+        parts.append(part)
+    off = 0
+    for x, c, part in zip(xd, cs, parts):
+        N.check(lib.wd_gn_apply(x.data_ptr(), c, B, hw, c, cpg, part.data_ptr(), nchunk, c // 32, gd.data_ptr(),
+                                bd.data_ptr(), eps, silu, pl[0].data_ptr(), pl[1].data_ptr(), ctot, off,
+                                raw[0].data_ptr(), raw[1].data_ptr(), _st()), "apply")
         off += c
     torch.cuda.synchronize()
     assert max_rel(unplanes(pl).cpu(), ref) < 3e-5
     assert max_rel(unplanes(raw).cpu(), torch.cat(xs, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("B,hh,ww,cin,n,ksplit", [(3, 8, 32, 64, 320, 1), (4, 4, 16, 320, 320, 1), (4, 4, 16, 320, 320, 0),
+                                                   (5, 8, 8, 64, 64, 1), (2, 8, 16, 64, 640, 1)])
+def test_gemm_fused_groupnorm_statistics(B, hh, ww, cin, n, ksplit):
+    """wd_gemm's epilogue statistics (stat_part) == sums over the finished output, and feed wd_gn_apply directly
+    (also as the 2x-coarser groups of a concat norm)."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(n + hh)
+    hw, m = hh * ww, B * hh * ww
+    a = torch.randn(m, cin, generator=g)
+    w = torch.randn(n, 9 * cin, generator=g) / (9 * cin) ** 0.5
+    bias, film = torch.randn(n, generator=g), torch.randn(B, n, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    args_keep = {}
+    cpg = n // 32
+    nchunk = max(1, hw // 128)
+    part = torch.full((B, nchunk, 32, 2), float("nan"), dtype=torch.float64, device=DEV)
+
+    lib_args = N.WdGemmArgs()
+    pl = planes_of(a.to(DEV))
+    tabd = torch.from_numpy(tab).to(DEV)
+    s0 = N.WdSrc()
+    s0.hi, s0.lo, s0.gather = pl[0].data_ptr(), pl[1].data_ptr(), tabd.data_ptr()
+    s0.ld, s0.c, s0.ntaps, s0.hw_src = cin, cin, 9, hw
+    lib_args.src[0] = s0
+    lib_args.nsrc, lib_args.npass = 1, 3
+    wp = planes_of(w.to(DEV))
+    lib_args.w_hi, lib_args.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
+    lib_args.m, lib_args.n, lib_args.ktot, lib_args.hw_out = m, n, 9 * cin, hw
+    bd, fd = bias.to(DEV), film.to(DEV)
+    lib_args.bias, lib_args.rowvec, lib_args.rowvec_ld = bd.data_ptr(), fd.data_ptr(), n
+    out = torch.zeros(m, n, device=DEV)
+    lib_args.out_f32, lib_args.out_ld = out.data_ptr(), n
+    lib_args.stat_part, lib_args.stat_cpg = part.data_ptr(), cpg
+    ws = torch.empty(8 * m * n, device=DEV)
+    lib_args.ksplit, lib_args.ws, lib_args.ws_floats = ksplit, ws.data_ptr(), ws.numel()
+    N.check(lib.wd_gemm(C.byref(lib_args), _st()), "wd_gemm+stats")
+    torch.cuda.synchronize()
+    o = out.cpu().double().reshape(B, hw, 32, cpg)
+    ref_sum = o.sum(dim=(1, 3))
+    ref_sq = (o * o).sum(dim=(1, 3))
+    got = part.cpu().sum(dim=1)
+    assert torch.isfinite(got).all()
+    assert max_rel(got[..., 0], ref_sum) < 1e-5 and max_rel(got[..., 1], ref_sq) < 1e-5
+    # consumer: GroupNorm + SiLU of this tensor as the first half of a 2n-channel concat norm (groups twice as wide)
+    other = torch.randn(m, n, generator=g)
+    gamma, beta = torch.randn(2 * n, generator=g), torch.randn(2 * n, generator=g)
+    cat = torch.cat([out.cpu(), other], 1).reshape(B, hw, 2 * n).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(cat.double(), 32, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).reshape(m, 2 * n)
+    opl = torch.zeros(2, m, 2 * n, dtype=torch.bfloat16, device=DEV)
+    gd, bd2, od = gamma.to(DEV), beta.to(DEV), other.to(DEV)
+    N.check(lib.wd_gn_apply(out.data_ptr(), n, B, hw, n, 2 * cpg, part.data_ptr(), nchunk, cpg, gd.data_ptr(),
+                            bd2.data_ptr(), 1e-5, 1, opl[0].data_ptr(), opl[1].data_ptr(), 2 * n, 0, None, None, _st()),
+            "apply")
+    nck = lib.wd_gn_nchunk(hw)
+    part2 = torch.zeros(B, nck, 32, 2, dtype=torch.float64, device=DEV)
+    N.check(lib.wd_gn_stats(od.data_ptr(), n, B, hw, n, cpg, part2.data_ptr(), _st()), "stats")
+    N.check(lib.wd_gn_apply(od.data_ptr(), n, B, hw, n, 2 * cpg, part2.data_ptr(), nck, cpg, gd.data_ptr(),
+                            bd2.data_ptr(), 1e-5, 1, opl[0].data_ptr(), opl[1].data_ptr(), 2 * n, n, None, None, _st()),
+            "apply2")
+    torch.cuda.synchronize()
+    assert max_rel(unplanes(opl).cpu(), ref) < 3e-5
 
 
 def test_layernorm_and_split():

@@ -36,14 +36,14 @@ class WdGemmArgs(C.Structure):
                 ("resid_rows", _vp), ("act", C.c_int32), ("out_f32", _vp), ("out_ld", C.c_int32),
                 ("out_hi", _vp), ("out_lo", _vp), ("out_pl_ld", C.c_int32), ("tile", C.c_int32),
                 ("w_layout", C.c_int32), ("slab_rows", C.c_int32), ("ksplit", C.c_int32), ("ws", _vp),
-                ("ws_floats", C.c_int64), ("dbg", C.c_int32)]
+                ("ws_floats", C.c_int64), ("stat_part", _vp), ("stat_cpg", C.c_int32), ("dbg", C.c_int32)]
 
 
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
     "wd_gn_nchunk": (_i, [_i]),
-    "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "wd_gn_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wd_gn_apply": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "wd_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wd_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "wd_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -26,14 +26,196 @@ constexpr int BK = 32;
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` inside a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
 
-// ---- vectorised epilogue shared by all kernels: the accumulators of all waves go through an fp32 LDS image of
-// the output tile (which also sums the two k-halves of the 8-wave variants), then every thread reads float4s
-// row-major and does bias / FiLM / residual / activation with 16-byte global loads and stores.
+// ---- epilogue shared by all kernels.  The accumulators of all waves go through an fp32 LDS image of the output
+// tile (which also sums the two k-halves of the 8-wave variants); wd_epilogue_from_image then reads float4s row-major
+// and does bias / FiLM / residual / activation with 16-byte global loads and stores, and - when the consumer is a
+// GroupNorm - reduces per-(sample, group) sum / sum of squares of the finished values in a fixed order, so that the
+// statistics pass over the feature map (wd_gn_stats) disappears.
+constexpr int WD_STAT_SCRATCH = 40 * 1024;  // LDS behind the epilogue image for the per-thread column sums
+constexpr int WD_STAT_MAXNS = 2;          // samples per 128-row panel the fused statistics support (hw_out >= 64)
+
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, float* ep, const int m0, const int n0,
+                                                       const int tid) {
+    constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
+    const bool geglu = a.act == WD_ACT_GEGLU;
+    const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
+    const int oc4 = ocols / 4;
+    const int nout = geglu ? a.n / 2 : a.n;
+    const int no0 = geglu ? n0 / 2 : n0;
+    const bool stats = a.stat_part != nullptr;
+    // 16-byte path needs aligned rows everywhere; otherwise (odd leading dimensions) one element at a time
+    const bool vec = (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
+                        reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32)) & 15) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0);
+    if (!vec) {
+        for (int i = tid; i < BM * ocols; i += NT) {
+            const int row = i / ocols, c = i - row * ocols;
+            const int m = m0 + row, no = no0 + c;
+            if (m >= a.m || no >= nout) continue;
+            float v;
+            if (geglu) {
+                const float x = ep[row * LDE + c] + (a.bias ? a.bias[n0 + c] : 0.f);
+                const float g = ep[row * LDE + c + BN / 2] + (a.bias ? a.bias[n0 + c + BN / 2] : 0.f);
+                v = x * wd_gelu_erf(g);
+            } else {
+                v = ep[row * LDE + c] + (a.bias ? a.bias[no] : 0.f);
+            }
+            if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
+            if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
+            if (a.act == WD_ACT_SILU) v = wd_silu(v);
+            if (stats) ep[row * LDE + c] = v;
+            if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
+            if (a.out_hi) {
+                uint32_t hb, lb;
+                wd_split1(v, hb, lb);
+                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
+                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)lb;
+            }
+        }
+    } else {
+        // thread -> (row lane, fixed column quad): coalesced rows, and per-thread column sums for the statistics
+        const int nrl = NT / oc4;                 // row lanes
+        const int rl = tid / oc4, c = (tid - rl * oc4) * 4;
+        const int no = no0 + c;
+        const int rps = BM > a.hw_out ? a.hw_out : BM;  // rows of one sample inside this panel
+        float* scr = ep + BM * LDE;               // statistics scratch [sample][row lane][BN][2]
+        float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+        int cur_s = 0;
+        if (rl < nrl && no < nout) {
+            float4 bx = make_float4(0, 0, 0, 0), bg = bx;
+            if (a.bias) {
+                bx = *reinterpret_cast<const float4*>(a.bias + (geglu ? n0 + c : no));
+                if (geglu) bg = *reinterpret_cast<const float4*>(a.bias + n0 + c + BN / 2);
+            }
+            for (int row = rl; row < BM; row += nrl) {
+                const int m = m0 + row;
+                if (m >= a.m) break;
+                float4 v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+                if (geglu) {  // columns [0, BN/2) of the tile are x, [BN/2, BN) their gates (weights packed that way)
+                    const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + c + BN / 2);
+                    v.x = (v.x + bx.x) * wd_gelu_erf(g.x + bg.x);
+                    v.y = (v.y + bx.y) * wd_gelu_erf(g.y + bg.y);
+                    v.z = (v.z + bx.z) * wd_gelu_erf(g.z + bg.z);
+                    v.w = (v.w + bx.w) * wd_gelu_erf(g.w + bg.w);
+                } else {
+                    v.x += bx.x; v.y += bx.y; v.z += bx.z; v.w += bx.w;
+                }
+                if (a.rowvec) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if (a.resid) {
+                    const long rr = a.resid_rows ? (long)a.resid_rows[m] : (long)m;
+                    const float4 q = *reinterpret_cast<const float4*>(a.resid + rr * a.resid_ld + no);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if (a.act == WD_ACT_SILU) {
+                    v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
+                }
+                if (stats) {
+                    const int sidx2 = row / rps;
+                    if (sidx2 != cur_s) {  // rows ascend: flush the finished sample's column sums
+                        float* o = scr + ((cur_s * nrl + rl) * BN + c) * 2;
+                        *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+                        *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
+                        ssum = make_float4(0.f, 0.f, 0.f, 0.f);
+                        ssq = ssum;
+                        cur_s = sidx2;
+                    }
+                    ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+                    ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+                }
+                if (no + 3 < nout) {
+                    if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
+                    if (a.out_hi) {
+                        uint2 hh, ll;
+                        wd_split4(v, hh, ll);
+                        *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
+                        if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + no) = ll;
+                    }
+                } else {  // ragged right edge (n not a multiple of 4 columns inside this float4)
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    for (int j = 0; j < 4 && no + j < nout; ++j) {
+                        if (a.out_f32) a.out_f32[(long)m * a.out_ld + no + j] = e[j];
+                        if (a.out_hi) {
+                            uint32_t hb, lb;
+                            wd_split1(e[j], hb, lb);
+                            a.out_hi[(long)m * a.out_pl_ld + no + j] = (wd_bf16)hb;
+                            if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no + j] = (wd_bf16)lb;
+                        }
+                    }
+                }
+            }
+        }
+        if (stats) {
+            // flush the running sample and zero-fill the (sample, row lane) slots this thread never reached
+            const int ns = BM > a.hw_out ? BM / a.hw_out : 1;
+            if (rl < nrl && c < BN) {
+                for (int s2 = cur_s; s2 < ns; ++s2) {
+                    float* o = scr + ((s2 * nrl + rl) * BN + c) * 2;
+                    const bool cur = (s2 == cur_s);
+                    *reinterpret_cast<float4*>(o) = cur ? make_float4(ssum.x, ssq.x, ssum.y, ssq.y) : make_float4(0, 0, 0, 0);
+                    *reinterpret_cast<float4*>(o + 4) = cur ? make_float4(ssum.z, ssq.z, ssum.w, ssq.w) : make_float4(0, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!stats) return;
+    // ---- GroupNorm partial statistics of the finished tile: (sample in panel, group) = fixed-order sum over the
+    // row lanes and the group's columns of the per-thread column sums above (host guarantees the vector path, BN % cpg
+    // == 0, n % cpg == 0, and that BM and hw_out divide one another).
+    __syncthreads();
+    {
+        const int cpg = a.stat_cpg;
+        const int ns = BM > a.hw_out ? BM / a.hw_out : 1;
+        const int rps = BM > a.hw_out ? a.hw_out : BM;
+        const int ngt = BN / cpg;
+        const int nrl = NT / oc4;
+        const float* scr = ep + BM * LDE;
+        const int nchunk = a.hw_out > BM ? a.hw_out / BM : 1;
+        const int ngs = a.n / cpg;  // groups per sample in the statistics array of this tensor
+        // level 1: (sample, group, row lane) -> sum over the group's columns, written back over the lane's first slot
+        float* scw = ep + BM * LDE;
+        for (int it = tid; it < ns * ngt * nrl; it += NT) {
+            const int l = it % nrl, g = (it / nrl) % ngt, sidx2 = it / (nrl * ngt);
+            const float* p = scr + ((sidx2 * nrl + l) * BN + g * cpg) * 2;
+            float su = 0.f, sq = 0.f;
+            for (int cc = 0; cc < cpg; ++cc) {
+                su += p[2 * cc];
+                sq += p[2 * cc + 1];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every read of this group's span precedes the write-back
+            scw[((sidx2 * nrl + l) * BN + g * cpg) * 2] = su;
+            scw[((sidx2 * nrl + l) * BN + g * cpg) * 2 + 1] = sq;
+        }
+        __syncthreads();
+        // level 2: (sample, group) -> sum over the row lanes in fixed order
+        for (int it = tid; it < ns * ngt; it += NT) {
+            const int g = it % ngt, sidx2 = it / ngt;
+            const int mrow = m0 + sidx2 * rps;
+            if (mrow >= a.m || n0 + g * cpg >= a.n) continue;
+            double su = 0.0, sq = 0.0;
+            for (int l = 0; l < nrl; ++l) {
+                const float* p = scr + ((sidx2 * nrl + l) * BN + g * cpg) * 2;
+                su += (double)p[0];
+                sq += (double)p[1];
+            }
+            const int b = mrow / a.hw_out;
+            const int chunk = (mrow - b * a.hw_out) / BM;
+            double* o = a.stat_part + (((long)b * nchunk + chunk) * ngs + n0 / cpg + g) * 2;
+            o[0] = su;
+            o[1] = sq;
+        }
+    }
+}
+
 template <int BM, int BN, int TN, int NT>
 __device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32x16 (&acc)[TN], char* smem, const int m0,
                                                 const int n0, const int wm, const int wn, const int wcols, const int kh,
                                                 const int nkh, const int tid, const int sidx = 0) {
-    constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
+    constexpr int LDE = BN + 4;
     float* ep = reinterpret_cast<float*>(smem);
     const int lane = tid & 63;
     const int frow = lane & 31, fhalf = lane >> 5;
@@ -68,99 +250,7 @@ __device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32
         }
         return;
     }
-    const bool geglu = a.act == WD_ACT_GEGLU;
-    const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
-    const int oc4 = ocols / 4;
-    const int nout = geglu ? a.n / 2 : a.n;
-    const int no0 = geglu ? n0 / 2 : n0;
-    // 16-byte path needs aligned rows everywhere; otherwise (odd leading dimensions) one element at a time
-    const bool vec = (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
-                     (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
-                        reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32)) & 15) == 0) &&
-                     (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0);
-    if (!vec) {
-        for (int i = tid; i < BM * ocols; i += NT) {
-            const int row = i / ocols, c = i - row * ocols;
-            const int m = m0 + row, no = no0 + c;
-            if (m >= a.m || no >= nout) continue;
-            float v;
-            if (geglu) {
-                const float x = ep[row * LDE + c] + (a.bias ? a.bias[n0 + c] : 0.f);
-                const float g = ep[row * LDE + c + BN / 2] + (a.bias ? a.bias[n0 + c + BN / 2] : 0.f);
-                v = x * wd_gelu_erf(g);
-            } else {
-                v = ep[row * LDE + c] + (a.bias ? a.bias[no] : 0.f);
-            }
-            if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
-            if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
-            if (a.act == WD_ACT_SILU) v = wd_silu(v);
-            if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
-            if (a.out_hi) {
-                uint32_t hb, lb;
-                wd_split1(v, hb, lb);
-                a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
-                if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no] = (wd_bf16)lb;
-            }
-        }
-        return;
-    }
-    for (int i = tid; i < BM * oc4; i += NT) {
-        const int row = i / oc4, c = (i - row * oc4) * 4;
-        const int m = m0 + row, no = no0 + c;
-        if (m >= a.m || no >= nout) continue;
-        float4 v;
-        if (geglu) {  // columns [0, BN/2) of the tile are x, [BN/2, BN) their gates (weights packed that way)
-            const float4 x = *reinterpret_cast<const float4*>(ep + row * LDE + c);
-            const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + c + BN / 2);
-            float4 bx = make_float4(0, 0, 0, 0), bg = bx;
-            if (a.bias) {
-                bx = *reinterpret_cast<const float4*>(a.bias + n0 + c);
-                bg = *reinterpret_cast<const float4*>(a.bias + n0 + c + BN / 2);
-            }
-            v.x = (x.x + bx.x) * wd_gelu_erf(g.x + bg.x);
-            v.y = (x.y + bx.y) * wd_gelu_erf(g.y + bg.y);
-            v.z = (x.z + bx.z) * wd_gelu_erf(g.z + bg.z);
-            v.w = (x.w + bx.w) * wd_gelu_erf(g.w + bg.w);
-        } else {
-            v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + no);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            }
-        }
-        if (a.rowvec) {
-            const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (a.resid) {
-            const long rr = a.resid_rows ? (long)a.resid_rows[m] : (long)m;
-            const float4 q = *reinterpret_cast<const float4*>(a.resid + rr * a.resid_ld + no);
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (a.act == WD_ACT_SILU) {
-            v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
-        }
-        if (no + 3 < nout) {
-            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
-            if (a.out_hi) {
-                uint2 hh, ll;
-                wd_split4(v, hh, ll);
-                *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
-                if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + no) = ll;
-            }
-        } else {  // ragged right edge (n not a multiple of 4 columns inside this float4)
-            const float e[4] = {v.x, v.y, v.z, v.w};
-            for (int j = 0; j < 4 && no + j < nout; ++j) {
-                if (a.out_f32) a.out_f32[(long)m * a.out_ld + no + j] = e[j];
-                if (a.out_hi) {
-                    uint32_t hb, lb;
-                    wd_split1(e[j], hb, lb);
-                    a.out_hi[(long)m * a.out_pl_ld + no + j] = (wd_bf16)hb;
-                    if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + no + j] = (wd_bf16)lb;
-                }
-            }
-        }
-    }
+    wd_epilogue_from_image<BM, BN, NT>(a, ep, m0, n0, tid);
 }
 
 template <int BM, int BN, int NPASS>
@@ -872,7 +962,7 @@ template <int BM, int BN, int NPASS, int SLABR, int KS>
 int launch3(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int loop_smem = 2 * NPL * (SLABR + 1) * 64 + RING3 * NPL * BN * 64 + 9 * BM * 4 + 64;
-    constexpr int red_smem = BM * (BN + 4) * 4;
+    constexpr int red_smem = BM * (BN + 4) * 4 + WD_STAT_SCRATCH;
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -893,7 +983,7 @@ template <int BM, int BN, int NPASS>
 int launch(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int loop_smem = 2 * NPL * (BM + BN) * 64;
-    constexpr int red_smem = BM * (BN + 4) * 4;
+    constexpr int red_smem = BM * (BN + 4) * 4 + WD_STAT_SCRATCH;
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;  // one process = one device, set once per instantiation
     if (!attr_done) {
@@ -908,33 +998,63 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
-// out = epilogue(sum of the ksplit partial slabs) - the same bias / FiLM / residual / activation / plane outputs as the
-// in-kernel epilogue, in a fixed summation order (deterministic).
-__global__ void wd_gemm_reduce_kernel(const wd_gemm_args a) {
+// out = epilogue(sum of the ksplit partial slabs): one workgroup per BM x BN tile sums the slabs in a fixed order into
+// the same fp32 LDS image the in-kernel epilogue uses and then runs that epilogue (statistics included).
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) wd_gemm_reduce_kernel(const wd_gemm_args a, const int nbn) {
+    constexpr int LDE = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ep = reinterpret_cast<float*>(smem);
+    const int bn_i = blockIdx.x % nbn, bm_i = blockIdx.x / nbn;
+    const int m0 = bm_i * BM, n0 = bn_i * BN;
+    const int tid = threadIdx.x;
     const long total = (long)a.m * a.n;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / a.n), n = (int)(i - (long)m * a.n);
-        float v = 0.f;
-        for (int sp = 0; sp < a.ksplit; ++sp) v += a.ws[(long)sp * total + i];
-        if (a.bias) v += a.bias[n];
-        if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + n];
-        if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + n];
-        if (a.act == WD_ACT_SILU) v = wd_silu(v);
-        if (a.out_f32) a.out_f32[(long)m * a.out_ld + n] = v;
-        if (a.out_hi) {
-            uint32_t hb, lb;
-            wd_split1(v, hb, lb);
-            a.out_hi[(long)m * a.out_pl_ld + n] = (wd_bf16)hb;
-            if (a.out_lo) a.out_lo[(long)m * a.out_pl_ld + n] = (wd_bf16)lb;
+    const bool v4 = (a.n & 3) == 0;
+    for (int i = tid; i < BM * (BN / 4); i += 256) {
+        const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+        const int m = m0 + row, n = n0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.m && n < a.n) {
+            if (v4) {
+                for (int sp = 0; sp < a.ksplit; ++sp) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.ws + (long)sp * total + (long)m * a.n + n);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+            } else {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int sp = 0; sp < a.ksplit; ++sp)
+                    for (int j = 0; j < 4 && n + j < a.n; ++j) e[j] += a.ws[(long)sp * total + (long)m * a.n + n + j];
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
         }
+        *reinterpret_cast<float4*>(ep + row * LDE + c) = v;
     }
+    __syncthreads();
+    wd_gemm_args b = a;
+    b.ksplit = 1;
+    wd_epilogue_from_image<BM, BN, 256>(b, ep, m0, n0, tid);
+}
+
+template <int RM, int RN>
+int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
+    constexpr int rsmem = RM * (RN + 4) * 4 + WD_STAT_SCRATCH;
+    static bool rattr = false;
+    if (!rattr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm_reduce_kernel<RM, RN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, rsmem) != hipSuccess)
+            return WD_ELAUNCH;
+        rattr = true;
+    }
+    const int rbn = (a.n + RN - 1) / RN, rbm = (a.m + RM - 1) / RM;
+    hipLaunchKernelGGL((wd_gemm_reduce_kernel<RM, RN>), dim3(rbn * rbm), dim3(256), rsmem, st, a, rbn);
+    return wd_check_launch();
 }
 
 template <int BM, int BN, int NPASS, int KS>
 int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int loop_smem = 2 * NPL * (BM + BN) * 128 + 9 * BM * 4;
-    constexpr int red_smem = BM * (BN + 4) * 4;  // the fp32 epilogue image overlays the stage buffers
+    constexpr int red_smem = BM * (BN + 4) * 4 + WD_STAT_SCRATCH;  // fp32 epilogue image (+ statistics scratch) overlays the stages
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
@@ -948,9 +1068,12 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
                        nbn, nbm);
     if (a.ksplit > 1) {
-        const long total = (long)a.m * a.n;
-        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(wd_gemm_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
+        // the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups
+        // per tile when the GroupNorm sums are fused in)
+        const int cpg = a.stat_part ? a.stat_cpg : 1;
+        if (40 % cpg == 0) return launch_reduce<128, 40>(a, st);
+        if (32 % cpg == 0) return launch_reduce<128, 32>(a, st);
+        return launch_reduce<BM, BN>(a, st);
     }
     return wd_check_launch();
 }
@@ -961,6 +1084,16 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
     wd_gemm_args a = *pa;
     if (a.ksplit < 0 || a.ksplit > 16) return WD_EINVAL;
+    if (a.stat_part) {
+        // fused GroupNorm statistics need 128-row panels that tile the samples and whole groups inside a column tile
+        if (a.stat_cpg <= 0 || a.n % a.stat_cpg || a.act == WD_ACT_GEGLU) return WD_EINVAL;
+        if (!((a.hw_out % 128 == 0) || (128 % a.hw_out == 0 && 128 / a.hw_out <= WD_STAT_MAXNS))) return WD_EINVAL;
+        const int bn = (a.tile ? a.tile % 1000 : (a.n % 160 == 0 ? 160 : 64));
+        const int bm = (a.tile ? a.tile / 1000 : 128);
+        if (bm != 128 || bn % a.stat_cpg) return WD_EINVAL;
+        if ((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) return WD_EINVAL;  // vector epilogue only
+        if (a.tile == 0) a.tile = bm * 1000 + bn;  // keep 128-row panels (no 64x64 fallback)
+    }
     if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout != 0)) return WD_EINVAL;
     if (a.w_layout != 0) a.ksplit = 1;
     if (a.nsrc < 1 || a.nsrc > 2 || (a.npass != 1 && a.npass != 3)) return WD_EINVAL;

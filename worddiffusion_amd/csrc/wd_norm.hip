@@ -9,7 +9,7 @@ namespace {
 constexpr int GN_TOK = 32;  // tokens per statistics chunk
 
 // grid (nchunk, batch); block (64 * ceil(c/4/64), 2).  thread x owns channels 4x..4x+3, y splits tokens.
-__global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int g0, int nchunk,
+__global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int nchunk,
                                 double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_sum = reinterpret_cast<float*>(smem);  // [2][c]
@@ -38,7 +38,7 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int
             ds += (double)s_sum[ch] + (double)s_sum[c + ch];
             dq += (double)s_sq[ch] + (double)s_sq[c + ch];
         }
-        double* o = part + (((long)b * nchunk + j) * 32 + g0 + tid) * 2;
+        double* o = part + (((long)b * nchunk + j) * ng + tid) * 2;
         o[0] = ds;
         o[1] = dq;
     }
@@ -46,7 +46,7 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int
 
 // grid (ceil(hw / TOK_PER_WG), batch), block 256.  One float4 (4 channels) per thread per step.
 constexpr int AP_TOK = 16;
-__global__ void gn_apply_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int g0, int nchunk,
+__global__ void gn_apply_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int nchunk, int part_cpg,
                                 const double* __restrict__ part, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, wd_bf16* __restrict__ out_hi,
                                 wd_bf16* __restrict__ out_lo, int out_ld, int c_off, wd_bf16* __restrict__ raw_hi,
@@ -55,11 +55,15 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, int ld, int hw, int
     const int b = blockIdx.y;
     const int ng = c / cpg;
     if (threadIdx.x < ng) {
+        // the statistics array holds c / part_cpg groups per (sample, chunk); this norm's group = `ratio` of them
+        const int ratio = cpg / part_cpg, ngs = c / part_cpg;
         double ds = 0.0, dq = 0.0;
         for (int j = 0; j < nchunk; ++j) {
-            const double* p = part + (((long)b * nchunk + j) * 32 + g0 + threadIdx.x) * 2;
-            ds += p[0];
-            dq += p[1];
+            const double* p = part + (((long)b * nchunk + j) * ngs + threadIdx.x * ratio) * 2;
+            for (int k = 0; k < ratio; ++k) {
+                ds += p[2 * k];
+                dq += p[2 * k + 1];
+            }
         }
         const double n = (double)hw * cpg;
         const double mean = ds / n;
@@ -175,30 +179,28 @@ __global__ void split_kernel(const float* __restrict__ x, int ld, int rows, int 
 
 extern "C" int wd_gn_nchunk(int hw) { return (hw + GN_TOK - 1) / GN_TOK; }
 
-extern "C" int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, double* part,
-                           void* stream) {
+extern "C" int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, double* part, void* stream) {
     if (!x || !part || batch <= 0 || hw <= 0 || c <= 0 || cpg <= 0) return WD_EINVAL;
-    if (c % 4 || ld % 4 || c % cpg || g0 < 0 || g0 + c / cpg > 32 || c > 4096) return WD_EINVAL;
+    if (c % 4 || ld % 4 || c % cpg || c / cpg > 256 || c > 4096) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = wd_gn_nchunk(hw);
     const int bx = 64 * ((c / 4 + 63) / 64);
     if (bx * 2 > 1024) return WD_EINVAL;
     WdLaunchScope scope(WD_CLS_GNSTATS, st);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(bx, 2), 4 * c * sizeof(float), st, x, ld, hw, c, cpg,
-                       g0, nchunk, part);
+                       nchunk, part);
     return wd_check_launch();
 }
 
-extern "C" int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, int g0, const double* part,
-                           const float* gamma, const float* beta, float eps, int silu, wd_bf16* out_hi,
+extern "C" int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, const double* part, int nchunk,
+                           int part_cpg, const float* gamma, const float* beta, float eps, int silu, wd_bf16* out_hi,
                            wd_bf16* out_lo, int out_ld, int c_off, wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream) {
-    if (!x || !part || !gamma || !beta || !out_hi || batch <= 0 || hw <= 0) return WD_EINVAL;
-    if (c % 4 || ld % 4 || out_ld % 4 || c_off % 4 || c % cpg || g0 < 0 || g0 + c / cpg > 32) return WD_EINVAL;
+    if (!x || !part || !gamma || !beta || !out_hi || batch <= 0 || hw <= 0 || nchunk <= 0 || part_cpg <= 0) return WD_EINVAL;
+    if (c % 4 || ld % 4 || out_ld % 4 || c_off % 4 || c % cpg || c / cpg > 32 || cpg % part_cpg) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_GNAPPLY, st);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch), dim3(256), 0, st, x, ld, hw, c, cpg,
-                       g0, wd_gn_nchunk(hw), part, gamma, beta, eps, silu, out_hi, out_lo, out_ld, c_off, raw_hi,
-                       raw_lo);
+                       nchunk, part_cpg, part, gamma, beta, eps, silu, out_hi, out_lo, out_ld, c_off, raw_hi, raw_lo);
     return wd_check_launch();
 }
 

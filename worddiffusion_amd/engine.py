@@ -111,10 +111,11 @@ def slab_span(tab: Optional[np.ndarray], hw_out: int, hw_src: int, m: int, bm: i
 
 class Act:
     """A token-major fp32 feature map [B*h*w, c] on the device."""
-    __slots__ = ("t", "c", "h", "w")
+    __slots__ = ("t", "c", "h", "w", "stats")
 
-    def __init__(self, t, c, h, w):
+    def __init__(self, t, c, h, w, stats=None):
         self.t, self.c, self.h, self.w = t, c, h, w
+        self.stats = stats  # (part tensor [B, nchunk, c / part_cpg, 2] f64, nchunk, part_cpg) once known
 
 
 class Plan:
@@ -155,6 +156,7 @@ class UNetEngine:
         self._w3: Dict[str, torch.Tensor] = {}      # slab-order copies of the matrices the v3 kernel consumes
         self._w3_meta: Dict[str, tuple] = {}
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
+        self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
@@ -368,7 +370,7 @@ class UNetEngine:
 
     def _gemm(self, ops, what, srcs, wname, m, hw_out, bias=None, rowvec=None, rowvec_ld=0, resid=None,
               resid_ld=0, resid_rows=None, act=N.ACT_NONE, out_f32=None, out_ld=0, out_pl=None, n=None, tile=0,
-              w_row_off=0):
+              w_row_off=0, want_stats=False):
         a = N.WdGemmArgs()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -407,6 +409,17 @@ class UNetEngine:
         if out_pl is not None:
             a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), out_pl[1].data_ptr(), out_pl.shape[2]
         a.tile = tile
+        stats = None
+        if want_stats and self.fuse_stats and nrows % 32 == 0 and (hw_out % 128 == 0 or hw_out == 64):
+            cpg = nrows // 32
+            bn = (tile % 1000) if tile else (160 if nrows % 160 == 0 else 64)
+            if bn % cpg == 0 and (tile == 0 or tile // 1000 == 128) and not span:
+                nchunk = max(1, hw_out // 128)
+                part = torch.zeros((m // hw_out, nchunk, 32, 2), dtype=torch.float64, device=self.device)
+                self._cur_plan.keep.append(part)
+                a.stat_part, a.stat_cpg = part.data_ptr(), cpg
+                stats = (part, nchunk, cpg)
+        a._stats = stats
         if self._ws is None:
             self._ws = torch.empty(128 * 128 * 160 * 8, dtype=torch.float32, device=self.device)  # 84 MB split-K scratch
         a.ksplit, a.ws, a.ws_floats = 0, self._ws.data_ptr(), self._ws.numel()
@@ -430,25 +443,27 @@ class UNetEngine:
                                                  B * hw), what + ":concat"))
                 coff += s.c
             srcs = [Act(cat, ctot, h, w)]
-        nchunk = self.lib.wd_gn_nchunk(hw)
-        part = torch.empty((B, nchunk, 32, 2), dtype=torch.float64, device=self.device)
-        P.keep.append(part)
         pl = self._planes(P, B * hw, ctot)
         raw = self._planes(P, B * hw, ctot) if want_raw else None
-        g0 = 0
         for s in srcs:
-            ops.append((self.lib.wd_gn_stats, (s.t.data_ptr(), s.c, B, hw, s.c, cpg, g0, part.data_ptr()),
-                        what + ":stats"))
-            g0 += s.c // cpg
-        g0 = coff = 0
+            if s.stats is None:  # no producer-side statistics: one pass over the tensor (32 groups of c/32 channels)
+                nchunk = self.lib.wd_gn_nchunk(hw)
+                pc = s.c // 32
+                part = torch.empty((B, nchunk, 32, 2), dtype=torch.float64, device=self.device)
+                P.keep.append(part)
+                ops.append((self.lib.wd_gn_stats, (s.t.data_ptr(), s.c, B, hw, s.c, pc, part.data_ptr()),
+                            what + ":stats"))
+                s.stats = (part, nchunk, pc)
+        coff = 0
         gam, bet = self._w[gname + ".g"], self._w[gname + ".b"]
         for s in srcs:
+            part, nchunk, pc = s.stats
+            assert cpg % pc == 0, (what, cpg, pc)
             ops.append((self.lib.wd_gn_apply,
-                        (s.t.data_ptr(), s.c, B, hw, s.c, cpg, g0, part.data_ptr(), gam.data_ptr(), bet.data_ptr(),
-                         eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None, ctot, coff,
-                         raw[0].data_ptr() if raw is not None else None,
+                        (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(),
+                         bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None,
+                         ctot, coff, raw[0].data_ptr() if raw is not None else None,
                          raw[1].data_ptr() if (raw is not None and self.npass == 3) else None), what + ":apply"))
-            g0 += s.c // cpg
             coff += s.c
         return pl, raw
 
@@ -471,19 +486,20 @@ class UNetEngine:
         need_raw = cin != cout
         a1, raw = self._gn(P, ops, name + ".gn1", srcs, name + ".gn1", 1e-5, True, want_raw=need_raw)
         h1 = self._f32(P, M, cout)
-        self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
-                   bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
-                   rowvec_ld=self.film_total, out_f32=h1, out_ld=cout)
-        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w)], name + ".gn2", 1e-5, True)
+        g1 = self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
+                        bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
+                        rowvec_ld=self.film_total, out_f32=h1, out_ld=cout, want_stats=True)
+        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w, g1._stats)], name + ".gn2", 1e-5, True)
         out = self._f32(P, M, cout)
         if need_raw:
-            self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
-                       name + ".c2.w", M, hw, bias=self._w[name + ".c2.b"], out_f32=out, out_ld=cout)
+            g2 = self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
+                            name + ".c2.w", M, hw, bias=self._w[name + ".c2.b"], out_f32=out, out_ld=cout,
+                            want_stats=True)
         else:
-            self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
-                       bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=out,
-                       out_ld=cout)
-        return Act(out, cout, h, w)
+            g2 = self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
+                            bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=out,
+                            out_ld=cout, want_stats=True)
+        return Act(out, cout, h, w, g2._stats)
 
     def _resample(self, P, name, mod, x: Act, mode: str) -> Act:
         ops = P.step
@@ -493,9 +509,9 @@ class UNetEngine:
         ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, B * x.h * x.w, x.c, 0, pl[0].data_ptr(),
                                         pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
         out = self._f32(P, B * ho * wo, mod.cout)
-        self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
-                   bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout)
-        return Act(out, mod.cout, ho, wo)
+        gg = self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
+                        bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True)
+        return Act(out, mod.cout, ho, wo, gg._stats)
 
     def _attention(self, ops, what, q, ldq, k, ldk, v, ldv, heads, nq, nk, d, scale, out_pl, out_f32=None,
                    out_rows=None, out_row0=0):
@@ -566,9 +582,10 @@ class UNetEngine:
                        resid=tok2.data_ptr(), resid_ld=inner, out_f32=None if last else tok, out_ld=inner,
                        out_pl=xpl)
         out = self._f32(P, M, c)
-        self._gemm(ops, name + ".proj_out", [self._src(xpl, inner)], name + ".po.w", M, hw,
-                   bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=out, out_ld=c)
-        return Act(out, c, h, w)
+        gg = self._gemm(ops, name + ".proj_out", [self._src(xpl, inner)], name + ".po.w", M, hw,
+                        bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=out, out_ld=c,
+                        want_stats=True)
+        return Act(out, c, h, w, gg._stats)
 
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int) -> Plan:
@@ -648,9 +665,9 @@ class UNetEngine:
         step.append((lib.wd_im2col3x3, (P.x_in.data_ptr(), B, m.in_channels, H, W, xin[0].data_ptr(),
                                         xin[1].data_ptr() if lo_ok else None, self.kpad_in), "im2col"))
         h0 = self._f32(P, B * H * W, mc)
-        self._gemm(step, "input_blocks.0", [self._src(xin, self.kpad_in)], "in.w", B * H * W, H * W,
-                   bias=self._w["in.b"], out_f32=h0, out_ld=mc)
-        cur = Act(h0, mc, H, W)
+        g0 = self._gemm(step, "input_blocks.0", [self._src(xin, self.kpad_in)], "in.w", B * H * W, H * W,
+                        bias=self._w["in.b"], out_f32=h0, out_ld=mc, want_stats=True)
+        cur = Act(h0, mc, H, W, g0._stats)
         hs = [cur]
 
         def run_layers(prefix, blk, cur, extra=None):
