@@ -148,15 +148,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    else:
+    from worddiffusion_amd import dist as wdist
+    rank, world, local = wdist.init_process_group("nccl")  # no-op for a single process
+    if world == 1:
         torch.cuda.set_device(0)
     dev = f"cuda:{local if world > 1 else 0}"
     B = a.batch
@@ -179,11 +173,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = wdist.max_over_ranks(elapsed, device=dev)
     ms_per_step = 1e3 * elapsed / a.steps
     finite = bool(torch.isfinite(runner.P.x_in).all().item())
 
