@@ -39,11 +39,12 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(dev, precision):
-    from worddiffusion_amd import UNetModel
+def build_model(dev, precision, variant="base"):
+    from worddiffusion_amd import UNetModel, UNetModelPhosc
     from worddiffusion_amd.synthetic import fill_module_
-    args = types.SimpleNamespace(device=dev, interpolation=False, latent=True, phosc=0, phos=0)
-    m = fill_module_(UNetModel(args=args, **FULL), 0).to(dev).eval()
+    args = types.SimpleNamespace(device=dev, interpolation=False, latent=True, phosc=1 if variant == "phosc" else 0, phos=0)
+    cls = UNetModel if variant == "base" else UNetModelPhosc
+    m = fill_module_(cls(args=args, **FULL), 0).to(dev).eval()
     m.set_precision(precision)
     return m, args
 
@@ -51,7 +52,7 @@ def build_model(dev, precision):
 class StepRunner:
     """The loop body of Diffusion.sampling, set up once so that K steps can be timed."""
 
-    def __init__(self, model, args, dev, batch, seed, sample_offset):
+    def __init__(self, model, args, dev, batch, seed, sample_offset, phosc_len=0):
         from worddiffusion_amd import Diffusion
         from worddiffusion_amd import _native as N
         from worddiffusion_amd.synthetic import synthetic_inputs
@@ -60,14 +61,15 @@ class StepRunner:
         self.diff = Diffusion(noise_steps=T, img_size=(64, 256), args=args)
         eng = model.engine
         eng.refresh_weights()
-        inp = synthetic_inputs(batch, seed=2 + sample_offset)
-        self.P = P = eng.plan(batch, 8, 32, 10, 0)
+        inp = synthetic_inputs(batch, seed=2 + sample_offset, phosc_len=phosc_len)
+        self.P = P = eng.plan(batch, 8, 32, 10, phosc_len)
         self.stream = torch.cuda.Stream(device=dev)
         self.ca, self.cb, self.cs = self.diff._step_tables(dev)
         with torch.cuda.stream(self.stream):
             st = self.stream.cuda_stream
             N.check(self.lib.wd_randn(P.x_in.data_ptr(), batch, P.x_in[0].numel(), seed, sample_offset, 0, st), "randn")
-            eng.load_inputs(P, None, None, inp["context"].to(dev), inp["y"].to(dev), None)
+            eng.load_inputs(P, None, None, inp["context"].to(dev), inp["y"].to(dev),
+                            inp["phosc"].to(dev) if phosc_len else None)
             self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self.reset_t()
             P.run_cond(st)
@@ -144,6 +146,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--variant", default="base", choices=["base", "phosc"],
+                    help="base = BASELINE configs[1] (the headline); phosc = UNetModelPhosc with a 769-int PHOSC vector "
+                         "(configs[4] model: 779-token context, 256-token self-attention), reported as an extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -155,8 +160,9 @@ def main():
     dev = f"cuda:{local if world > 1 else 0}"
     B = a.batch
 
-    model, args = build_model(dev, a.precision)
-    runner = StepRunner(model, args, dev, B, seed=1234, sample_offset=rank * B)
+    model, args = build_model(dev, a.precision, a.variant)
+    runner = StepRunner(model, args, dev, B, seed=1234, sample_offset=rank * B,
+                        phosc_len=769 if a.variant == "phosc" else 0)
     runner.capture()
     runner.run(a.warmup)
     torch.cuda.synchronize()
@@ -209,7 +215,7 @@ def main():
                       for i in range(N.NCLASS)}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.variant == "base":
         cpu = cpu_baseline(min(os.cpu_count() or 1, 64))
 
     if rank == 0:
@@ -221,7 +227,7 @@ def main():
                     config=dict(workload="BASELINE configs[1]: batch 64 per GPU of 64x256 crops = [64,4,8,32] latents, "
                                          "1000-step DDPM (999 executed steps), base unet.py UNetModel (320 ch, mult (1,1), "
                                          "4 heads, 339 writers), random-init synthetic weights",
-                                batch_per_gpu=B, noise_steps=T, executed_steps_per_image=T - 1, forwards_per_step=1,
+                                variant=a.variant, batch_per_gpu=B, noise_steps=T, executed_steps_per_image=T - 1, forwards_per_step=1,
                                 precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
                                 images_per_sec_per_gpu=value / world, output_finite=finite),
