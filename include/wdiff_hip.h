@@ -177,6 +177,21 @@ int wd_copy2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, 
 /* EMA of weights, train.py:151-159: ema = ema * beta + (1 - beta) * p over one flat fp32 buffer. */
 int wd_ema_update(float* ema, const float* p, int64_t n, double beta, void* stream);
 
+/* Multi-tensor fused AdamW (+ EMA of the weights) - the optimiser side of the training step, train.py:290-294,405,146-170.
+ * table: device array of ntensor records {float* p; const float* g; float* m; float* v; float* ema (or NULL);
+ * int64 n; int64 chunk0} (wd_adamw_table_entry_bytes() each), chunk0 = running sum of ceil(n / wd_adamw_chunk());
+ * total_chunks = that sum over all tensors.  Same fp32 op order as torch.optim.AdamW's single-tensor update at `step`
+ * (1-based).  ema_mode 0: none, 1: ema = p (the first 2000 steps of the reference), 2: ema = ema*beta + (1-beta)*p. */
+int wd_adamw_table_entry_bytes(void);
+int wd_adamw_chunk(void);
+int wd_adamw_multi(const void* table, int ntensor, int64_t total_chunks, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, int ema_mode, double ema_beta, void* stream);
+
+/* loss = mean((pred - target)^2) (nn.MSELoss, train.py:289; deterministic two-stage sum) and, when grad != NULL,
+ * grad = d loss / d pred = 2 (pred - target) / n.  scratch: >= min(1024, ceil(n/256)) doubles. */
+int wd_mse_loss(const float* pred, const float* target, int64_t n, float* grad, float* loss, double* scratch,
+                int scratch_len, void* stream);
+
 /* hipGraph capture of a launch sequence (one denoising step) on `stream`. */
 int wd_graph_begin(void* stream);
 int wd_graph_end(void* stream, void** graph_exec_out);

@@ -198,3 +198,50 @@ def test_full_size_properties_b64():
     with torch.no_grad():
         ref = orc(inp["x"][:2], inp["t"][:2], inp["context"][:2], inp["y"][:2])
     assert max_rel(o1[:2].cpu(), ref) < 1e-4
+
+
+def test_optimizer_side_of_train_step(golden_dir):
+    """MSE loss / gradient and the fused AdamW(+EMA) launch against the reference's own train step
+    (tests/golden/train_step.npz: loss, AdamW-updated tensors) and torch.optim.AdamW semantics."""
+    from worddiffusion_amd.optim import FusedAdamW, mse_loss
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    g = load_golden(golden_dir, "train_step")
+    pred, eps = torch.from_numpy(g["pred"]).to(DEV), torch.from_numpy(g["eps"]).to(DEV)
+    loss, grad = mse_loss(pred, eps)
+    assert abs(float(loss.item()) - float(g["loss"])) < 1e-6
+    ref_grad = 2 * (pred - eps) / pred.numel()
+    assert max_rel(grad.cpu(), ref_grad.cpu()) < 1e-6
+    # AdamW step 1 with the reference's gradients on the four tensors the golden file carries
+    keys = [n[6:] for n in g.files if n.startswith("adamw:")]
+    shapes = dict(U.state_dict_shapes(SMALL, "phosc"))
+    params = [torch.nn.Parameter(torch.from_numpy(synthetic_tensor(k, shapes[k], int(g["seed_model"]))).to(DEV)) for k in keys]
+    for p, k in zip(params, keys):
+        p.grad = torch.from_numpy(g["grad:" + k]).to(DEV)
+    ema_params = [torch.nn.Parameter(torch.zeros_like(p)) for p in params]
+
+    class Holder(torch.nn.Module):
+        def __init__(self, ps):
+            super().__init__()
+            self.ps = torch.nn.ParameterList(ps)
+
+    opt = FusedAdamW(params, lr=1e-4, ema_model=Holder(ema_params), ema_beta=0.995, step_start_ema=1)
+    opt.step()
+    for p, e, k in zip(params, ema_params, keys):
+        assert max_rel(p.detach().cpu(), g["adamw:" + k]) < 1e-6, k
+        assert torch.equal(e.detach(), p.detach())  # warm-up step: plain copy
+    # second step against torch.optim.AdamW on the CPU, EMA now averaging
+    cpu = [torch.nn.Parameter(torch.from_numpy(synthetic_tensor(k, shapes[k], int(g["seed_model"])))) for k in keys]
+    ref_opt = torch.optim.AdamW(cpu, lr=1e-4)
+    for step in range(2):
+        for c, p, k in zip(cpu, params, keys):
+            gr = torch.from_numpy(g["grad:" + k]) * (1.0 + step)
+            c.grad = gr.clone()
+            p.grad.copy_(gr.to(DEV))
+        ref_opt.step()
+        if step == 1:
+            before = [e.detach().clone() for e in ema_params]
+            opt.step()
+    for c, p, e, b in zip(cpu, params, ema_params, before):
+        assert max_rel(p.detach().cpu(), c.detach()) < 1e-6
+        ref_e = b.cpu() * 0.995 + (1 - 0.995) * p.detach().cpu()
+        assert max_rel(e.detach().cpu(), ref_e) < 1e-6

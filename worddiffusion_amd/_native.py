@@ -58,6 +58,11 @@ _SIGS = {
     "wd_noise_images": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wd_copy2d": (_i, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "wd_ema_update": (_i, [_vp, _vp, C.c_int64, C.c_double, _vp]),
+    "wd_adamw_table_entry_bytes": (_i, []),
+    "wd_adamw_chunk": (_i, []),
+    "wd_adamw_multi": (_i, [_vp, _i, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, _i,
+                           C.c_double, _vp]),
+    "wd_mse_loss": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _i, _vp]),
     "wd_graph_begin": (_i, [_vp]),
     "wd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "wd_graph_launch": (_i, [_vp, _vp]),
