@@ -192,6 +192,60 @@ int wd_adamw_multi(const void* table, int ntensor, int64_t total_chunks, double 
 int wd_mse_loss(const float* pred, const float* target, int64_t n, float* grad, float* loss, double* scratch,
                 int scratch_len, void* stream);
 
+/* ---- backward building blocks (training step, train.py:290: loss.backward()).  Contractions reuse wd_gemm:
+ *  d(input)  = wd_gemm over d(output) planes with the mirrored gather table and transposed weights;
+ *  d(weight) = wd_gemm over the token dimension, operands = the transposed planes made by wd_transpose_planes. */
+
+/* out[(t*c + ch)][mm] = in[src(mm, t)][ch] for mm < m (0 beyond, up to mpad): split-bf16 planes [ntaps*c][mpad].
+ * in: planes (in_is_f32 = 0; in_lo may be NULL) or one fp32 matrix (in_is_f32 = 1, split on the fly); src = row mm, or
+ * through the 3x3 gather table as in wd_gemm (zero row for -1). */
+int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int ld, int c, const int32_t* gather, int ntaps,
+                        int hw_out, int hw_src, int m, int mpad, wd_bf16* out_hi, wd_bf16* out_lo, void* stream);
+
+/* out[s][col] (+)= scale * sum over rows [s*seg, (s+1)*seg) of x[row][col]; fixed summation order.
+ * scratch: ceil(rows/seg) * ceil(seg/64) * c floats.  (bias gradients: seg = rows; FiLM gradient: seg = hw.) */
+int wd_colsum(const float* x, int ld, int rows, int c, int seg, float* out, int out_ld, int accumulate, float scale,
+              float* scratch, int64_t scratch_floats, void* stream);
+
+/* GroupNorm (+SiLU) backward (unet.py:427-431,594,618 through autograd).  x: the forward input, dz: gradient w.r.t. the
+ * normalised(+SiLU) output, columns [dz_off, dz_off + c) of a [B*hw][dz_ld] matrix (channel concat: one call per source);
+ * part / nchunk_f / part_cpg: the forward statistics as for wd_gn_apply.
+ * pass 1 -> sums[b][chunk][2][c] (chunk < wd_gn_bwd_nchunk(hw)): per-channel sums of dy and dy*xhat; their column sums over
+ * (b, chunk) are [d beta | d gamma].  pass 2 -> dx (+= when accumulate). */
+int wd_gn_bwd_nchunk(int hw);
+int wd_gn_bwd_stats(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c, int cpg,
+                    const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off, float eps,
+                    int silu, float* sums, void* stream);
+int wd_gn_bwd_apply(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c, int cpg,
+                    const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off, float eps,
+                    int silu, const float* sums, float* dx, int dx_ld, int accumulate, void* stream);
+
+/* LayerNorm backward: dx (+=), and colpart[blk][2][c] (blk < wd_layernorm_bwd_nblk(rows)) whose column sums are
+ * [d gamma | d beta]. */
+int wd_layernorm_bwd_nblk(int rows);
+int wd_layernorm_bwd(const float* x, int ld, const float* dy, int dy_ld, int rows, int c, const float* gamma, float eps,
+                     float* dx, int dx_ld, int accumulate, float* colpart, void* stream);
+
+/* softmax-attention backward for nk <= 16 keys: dq[B*nq][lddq]; dkv_part[b][nwg][2][nk][heads*d] = per-workgroup partial
+ * sums of (dK, dV) over their tokens (nwg returned; the caller column-sums them). */
+/* number of per-workgroup dK/dV partial slabs wd_attention_bwd_small writes per batch element (0 = unsupported shape) */
+int wd_attention_bwd_small_nwg(int heads, int nq, int nk, int d);
+int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout,
+                           int ldo, int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq,
+                           float* dkv_part, int* nwg_out, void* stream);
+
+/* GEGLU unfused (training keeps the pre-activation u = [a | g]): h = a * gelu_erf(g) -> planes; du from dh. */
+int wd_geglu_fwd(const float* u, int ld, int64_t rows, int inner, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
+int wd_geglu_bwd(const float* u, int ld, const float* dh, int dh_ld, int64_t rows, int inner, float* du, int du_ld,
+                 void* stream);
+/* dpre = dact * silu'(pre) */
+int wd_silu_bwd(const float* pre, const float* dact, int64_t n, float* dpre, void* stream);
+/* backward of nearest x2 upsampling: in [B][2h][2w][c] -> out [B][h][w][c], 2x2 block sums */
+int wd_pool2x2_sum(const float* in, int batch, int h, int w, int c, float* out, void* stream);
+/* nn.Embedding backward: dtable[v][:] (+)= sum of d[r][:] over rows with ids[r] == v (deterministic) */
+int wd_embedding_bwd(const void* ids, int ids_are_i64, int rows, const float* d, int ld, int vocab, int c, float* dtable,
+                     int accumulate, void* stream);
+
 /* hipGraph capture of a launch sequence (one denoising step) on `stream`. */
 int wd_graph_begin(void* stream);
 int wd_graph_end(void* stream, void** graph_exec_out);

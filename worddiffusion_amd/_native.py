@@ -63,6 +63,21 @@ _SIGS = {
     "wd_adamw_multi": (_i, [_vp, _i, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, _i,
                            C.c_double, _vp]),
     "wd_mse_loss": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _i, _vp]),
+    "wd_transpose_planes": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wd_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, C.c_int64, _vp]),
+    "wd_gn_bwd_nchunk": (_i, [_i]),
+    "wd_gn_bwd_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp]),
+    "wd_gn_bwd_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _i, _i, _vp]),
+    "wd_layernorm_bwd_nblk": (_i, [_i]),
+    "wd_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _vp]),
+    "wd_attention_bwd_small_nwg": (_i, [_i, _i, _i, _i]),
+    "wd_attention_bwd_small": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp,
+                                   C.POINTER(_i), _vp]),
+    "wd_geglu_fwd": (_i, [_vp, _i, C.c_int64, _i, _vp, _vp, _i, _vp]),
+    "wd_geglu_bwd": (_i, [_vp, _i, _vp, _i, C.c_int64, _i, _vp, _i, _vp]),
+    "wd_silu_bwd": (_i, [_vp, _vp, C.c_int64, _vp, _vp]),
+    "wd_pool2x2_sum": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "wd_embedding_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "wd_graph_begin": (_i, [_vp]),
     "wd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "wd_graph_launch": (_i, [_vp, _vp]),

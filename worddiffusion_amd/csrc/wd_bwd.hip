@@ -1,0 +1,663 @@
+// Backward building blocks of the training step (SURVEY.md row a-T; reference: loss.backward() of train.py:290-292 through
+// unet.py's ResBlock / SpatialTransformer / CrossAttention / GEGLU modules).  All contractions of the backward pass run
+// on wd_gemm (data gradients: mirrored gather tables + transposed weights; weight gradients: a GEMM over the token
+// dimension whose operands are the TRANSPOSED planes produced here).  This file holds the non-GEMM pieces:
+//   wd_transpose_planes   planes / fp32 [rows][C] (+ 3x3 tap gather) -> planes [taps*C][M]   (operands of the dW GEMMs)
+//   wd_colsum             deterministic (segmented) column sums: bias, FiLM and affine-parameter gradients
+//   wd_gn_bwd_stats/apply GroupNorm(+SiLU) backward
+//   wd_layernorm_bwd      LayerNorm backward
+//   wd_attention_bwd_small  softmax attention backward for <= 16 keys (the 10 text tokens)
+//   wd_geglu_fwd/bwd, wd_silu_bwd, wd_pool2x2_sum (nearest-x2 upsample backward), wd_embedding_bwd
+// Reductions are two-stage with fixed order (no float atomics): gradients are bitwise reproducible.
+#include "wd_common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_grad(float y) {  // d silu(y) / dy
+    const float s = 1.0f / (1.0f + expf(-y));
+    return s * (1.0f + y * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_grad(float g) {  // d gelu_erf(g) / dg
+    const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+    return cdf + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+}
+
+// ---- transpose: out[(t*C + c)][m] = in[src(m, t)][c]   (64 x 64 tiles through LDS; src = gather table or identity)
+template <bool F32IN>
+__global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __restrict__ in_hi, const void* __restrict__ in_lo,
+                                                               int ld, int c, const int32_t* __restrict__ gather, int ntaps,
+                                                               int hw_out, int hw_src, int m, int mpad,
+                                                               wd_bf16* __restrict__ out_hi, wd_bf16* __restrict__ out_lo) {
+    __shared__ wd_bf16 th[64][66], tl[64][66];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int r = ty; r < 64; r += 4) {       // r: token inside the tile, tx: channel
+        const int mm = m0 + r, cc = c0 + tx;
+        uint32_t h = 0, l = 0;
+        if (mm < m && cc < c) {
+            long src = mm;
+            if (gather) {
+                const int b = mm / hw_out, p = mm - b * hw_out;
+                const int g = gather[tap * hw_out + p];
+                src = g >= 0 ? (long)b * hw_src + g : -1;
+            }
+            if (src >= 0) {
+                if (F32IN) {
+                    wd_split1(reinterpret_cast<const float*>(in_hi)[src * ld + cc], h, l);
+                } else {
+                    h = reinterpret_cast<const wd_bf16*>(in_hi)[src * ld + cc];
+                    if (in_lo) l = reinterpret_cast<const wd_bf16*>(in_lo)[src * ld + cc];
+                }
+            }
+        }
+        th[r][tx] = (wd_bf16)h;
+        tl[r][tx] = (wd_bf16)l;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {       // r: channel inside the tile, tx: token
+        const int cc = c0 + r, mm = m0 + tx;
+        if (cc < c && mm < mpad) {
+            const long o = ((long)tap * c + cc) * mpad + mm;
+            out_hi[o] = th[tx][r];
+            if (out_lo) out_lo[o] = tl[tx][r];
+        }
+    }
+}
+
+// ---- column sums of x[rows][ld] over row segments of `seg` rows: out[s][c] (+= when accumulate), two stages
+constexpr int CS_ROWS = 64;
+__global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ x, int ld, int rows, int c, int seg,
+                                                     float* __restrict__ part) {
+    // grid (ceil(seg / CS_ROWS), nseg, ceil(c / 256)); one thread per column, CS_ROWS rows per block
+    const int col = blockIdx.z * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    const int r0 = s * seg + blockIdx.x * CS_ROWS, r1 = min(min(r0 + CS_ROWS, (s + 1) * seg), rows);
+    if (col >= c) return;
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += x[(long)r * ld + col];
+    part[((long)s * gridDim.x + blockIdx.x) * c + col] = acc;
+}
+__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ part, int nblk, int c, int nseg,
+                                                     float* __restrict__ out, int out_ld, int accumulate, float scale) {
+    const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (col >= c) return;
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) acc += (double)part[((long)s * nblk + k) * c + col];
+    const float v = (float)acc * scale;
+    float* o = out + (long)s * out_ld + col;
+    *o = accumulate ? *o + v : v;
+}
+
+// ---- GroupNorm (+SiLU) backward, pass 1: per (sample, chunk, channel) sums of dy and dy * xhat,
+// sums[b][chunk][2][c] (planar: row-summing it gives [d beta | d gamma])
+constexpr int GB_TOK = 32;
+__global__ void gn_bwd_stats_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dz, int dz_ld,
+                                    int dz_off, int hw, int c, int cpg, const double* __restrict__ part, int nchunk_f,
+                                    int part_cpg, const float* __restrict__ gamma, const float* __restrict__ beta, int c_off,
+                                    float eps, int silu, int nchunk, float* __restrict__ sums) {
+    // grid (nchunk, batch), block (64 * ceil(c/4/64), 2); sums: [b][chunk][2][c] (planar)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_mean = reinterpret_cast<float*>(smem);
+    float* s_rstd = s_mean + 32;
+    float* s_acc = s_rstd + 32;  // [2 (y)][c][2]
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int ng = c / cpg;
+    if (tid < ng) {
+        const int ratio = cpg / part_cpg, ngs = c / part_cpg;
+        double ds = 0.0, dq = 0.0;
+        for (int k = 0; k < nchunk_f; ++k) {
+            const double* p = part + (((long)b * nchunk_f + k) * ngs + tid * ratio) * 2;
+            for (int q = 0; q < ratio; ++q) {
+                ds += p[2 * q];
+                dq += p[2 * q + 1];
+            }
+        }
+        const double n = (double)hw * cpg, mean = ds / n;
+        double var = dq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cx = threadIdx.x * 4;
+    if (cx < c) {
+        const int t0 = j * GB_TOK, t1 = min(hw, t0 + GB_TOK);
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c_off + cx);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c_off + cx);
+        const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+        for (int t = t0 + threadIdx.y; t < t1; t += 2) {
+            const long row = (long)b * hw + t;
+            const float4 xv = *reinterpret_cast<const float4*>(x + row * ld + cx);
+            const float4 dv = *reinterpret_cast<const float4*>(dz + row * dz_ld + dz_off + cx);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds4[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = (cx + k) / cpg;
+                const float xh = (xs[k] - s_mean[g]) * s_rstd[g];
+                float dy = ds4[k];
+                if (silu) dy *= silu_grad(gam[k] * xh + bet[k]);
+                s1[k] += dy;
+                s2[k] += dy * xh;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_acc[(threadIdx.y * c + cx + k) * 2] = s1[k];
+            s_acc[(threadIdx.y * c + cx + k) * 2 + 1] = s2[k];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < c; i += blockDim.x * blockDim.y) {
+        float* o = sums + ((long)b * nchunk + j) * 2 * c + i;  // [b][chunk][{sum dy, sum dy*xhat}][c]
+        o[0] = s_acc[i * 2] + s_acc[(c + i) * 2];
+        o[c] = s_acc[i * 2 + 1] + s_acc[(c + i) * 2 + 1];
+    }
+}
+
+// pass 2: dx = rstd * (gamma dy - m1_g - xhat m2_g),  m1_g = mean_g(gamma dy), m2_g = mean_g(gamma dy xhat)
+constexpr int GA_TOK = 16;
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dz, int dz_ld, int dz_off,
+                                    int hw, int c, int cpg, const double* __restrict__ part, int nchunk_f, int part_cpg,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, int c_off, float eps,
+                                    int silu, const float* __restrict__ sums, int nchunk, float* __restrict__ dx, int dx_ld,
+                                    int accumulate) {
+    __shared__ float s_mean[32], s_rstd[32], s_m1[32], s_m2[32];
+    const int b = blockIdx.y;
+    const int ng = c / cpg;
+    if (threadIdx.x < ng) {
+        const int g = threadIdx.x;
+        const int ratio = cpg / part_cpg, ngs = c / part_cpg;
+        double ds = 0.0, dq = 0.0;
+        for (int k = 0; k < nchunk_f; ++k) {
+            const double* p = part + (((long)b * nchunk_f + k) * ngs + g * ratio) * 2;
+            for (int q = 0; q < ratio; ++q) {
+                ds += p[2 * q];
+                dq += p[2 * q + 1];
+            }
+        }
+        const double n = (double)hw * cpg, mean = ds / n;
+        double var = dq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        double a1 = 0.0, a2 = 0.0;
+        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = 0; k < nchunk; ++k) {
+                const float* s = sums + ((long)b * nchunk + k) * 2 * c + cc;
+                t1 += (double)s[0];
+                t2 += (double)s[c];
+            }
+            a1 += (double)gamma[c_off + cc] * t1;
+            a2 += (double)gamma[c_off + cc] * t2;
+        }
+        s_m1[g] = (float)(a1 / n);
+        s_m2[g] = (float)(a2 / n);
+    }
+    __syncthreads();
+    const int c4 = c >> 2;
+    const int t0 = blockIdx.x * GA_TOK, nt = min(GA_TOK, hw - t0);
+    for (int i = threadIdx.x; i < nt * c4; i += blockDim.x) {
+        const int t = i / c4, cx = (i - t * c4) * 4;
+        const long row = (long)b * hw + t0 + t;
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * ld + cx);
+        const float4 dv = *reinterpret_cast<const float4*>(dz + row * dz_ld + dz_off + cx);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c_off + cx);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c_off + cx);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds4[4] = {dv.x, dv.y, dv.z, dv.w};
+        const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (cx + k) / cpg;
+            const float xh = (xs[k] - s_mean[g]) * s_rstd[g];
+            float dy = ds4[k];
+            if (silu) dy *= silu_grad(gam[k] * xh + bet[k]);
+            o[k] = s_rstd[g] * (gam[k] * dy - s_m1[g] - xh * s_m2[g]);
+        }
+        float4* op = reinterpret_cast<float4*>(dx + row * dx_ld + cx);
+        float4 r = make_float4(o[0], o[1], o[2], o[3]);
+        if (accumulate) {
+            const float4 old = *op;
+            r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+        }
+        *op = r;
+    }
+}
+
+// ---- LayerNorm backward: one wave per row; a block walks LB_ROWS rows and emits per-column partial sums of
+// dy * xhat (-> d gamma) and dy (-> d beta): colpart[blk][c][2]
+constexpr int LB_MAX4 = 8;
+constexpr int LB_ROWS = 64;
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy,
+                                                            int dy_ld, int rows, int c, const float* __restrict__ gamma,
+                                                            float eps, float* __restrict__ dx, int dx_ld, int accumulate,
+                                                            float* __restrict__ colpart) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_col = reinterpret_cast<float*>(smem);  // [4 waves][c][2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = c >> 2;
+    float4 ag[LB_MAX4], ab[LB_MAX4];
+#pragma unroll
+    for (int i = 0; i < LB_MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r0 = blockIdx.x * LB_ROWS;
+    for (int rr = wave; rr < LB_ROWS; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= rows) break;
+        float4 v[LB_MAX4], d[LB_MAX4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LB_MAX4; ++i) {
+            const int f = lane + 64 * i;
+            if (f < c4) {
+                v[i] = *reinterpret_cast<const float4*>(x + (long)row * ld + f * 4);
+                d[i] = *reinterpret_cast<const float4*>(dy + (long)row * dy_ld + f * 4);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        const float mean = wd_wave_sum(s) / (float)c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LB_MAX4; ++i) {
+            const int f = lane + 64 * i;
+            if (f < c4) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)c + eps);
+        float t1 = 0.f, t2 = 0.f;  // sum(dxhat), sum(dxhat * xhat)
+#pragma unroll
+        for (int i = 0; i < LB_MAX4; ++i) {
+            const int f = lane + 64 * i;
+            if (f < c4) {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
+                float4 xh;
+                xh.x = (v[i].x - mean) * rstd; xh.y = (v[i].y - mean) * rstd;
+                xh.z = (v[i].z - mean) * rstd; xh.w = (v[i].w - mean) * rstd;
+                ag[i].x += d[i].x * xh.x; ag[i].y += d[i].y * xh.y; ag[i].z += d[i].z * xh.z; ag[i].w += d[i].w * xh.w;
+                ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+                d[i].x *= ga.x; d[i].y *= ga.y; d[i].z *= ga.z; d[i].w *= ga.w;  // dxhat
+                t1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                t2 += (d[i].x * xh.x + d[i].y * xh.y) + (d[i].z * xh.z + d[i].w * xh.w);
+                v[i] = xh;
+            }
+        }
+        t1 = wd_wave_sum(t1) / (float)c;
+        t2 = wd_wave_sum(t2) / (float)c;
+#pragma unroll
+        for (int i = 0; i < LB_MAX4; ++i) {
+            const int f = lane + 64 * i;
+            if (f < c4) {
+                float4 o;
+                o.x = rstd * (d[i].x - t1 - v[i].x * t2); o.y = rstd * (d[i].y - t1 - v[i].y * t2);
+                o.z = rstd * (d[i].z - t1 - v[i].z * t2); o.w = rstd * (d[i].w - t1 - v[i].w * t2);
+                float4* op = reinterpret_cast<float4*>(dx + (long)row * dx_ld + f * 4);
+                if (accumulate) {
+                    const float4 old = *op;
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *op = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LB_MAX4; ++i) {
+        const int f = lane + 64 * i;
+        if (f < c4) {
+            *reinterpret_cast<float4*>(s_col + (wave * 2) * c + f * 4) = ag[i];      // [wave][{d gamma, d beta}][c]
+            *reinterpret_cast<float4*>(s_col + (wave * 2 + 1) * c + f * 4) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c * 2; i += 256) {
+        const float v = (s_col[i] + s_col[c * 2 + i]) + (s_col[2 * c * 2 + i] + s_col[3 * c * 2 + i]);
+        colpart[(long)blockIdx.x * c * 2 + i] = v;
+    }
+}
+
+// ---- attention backward, few keys: thread = (token, head); dq written per token; dK / dV reduced over the
+// workgroup's tokens through LDS in fixed order and written as per-workgroup partials [b][nwg][2][nk][inner]
+constexpr int NKB = 16;
+__global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                             int ldk, const float* __restrict__ v, int ldv,
+                                                             const float* __restrict__ dout, int ldo, int heads, int nq,
+                                                             int nk, int d, float scale, float* __restrict__ dq, int lddq,
+                                                             float* __restrict__ dkv_part, int tpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int inner = heads * d;
+    float* s_k = reinterpret_cast<float*>(smem);   // [nk][inner]
+    float* s_v = s_k + nk * inner;                 // [nk][inner]
+    float* s_red = s_v + nk * inner;               // [tpw][inner + 4]: per-token contribution of one key
+    const int pitch = inner + 4;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int i4 = inner >> 2;
+    const int tok0 = blockIdx.x * tpw, ntok = min(tpw, nq - tok0);
+    for (int e = tid; e < nk * i4; e += 256) {
+        const int j = e / i4, c = (e - j * i4) * 4;
+        *reinterpret_cast<float4*>(s_k + j * inner + c) = *reinterpret_cast<const float4*>(k + ((long)b * nk + j) * ldk + c);
+        *reinterpret_cast<float4*>(s_v + j * inner + c) = *reinterpret_cast<const float4*>(v + ((long)b * nk + j) * ldv + c);
+    }
+    __syncthreads();
+    const int h = tid % heads, tl = tid / heads;
+    const bool act = tl < ntok;
+    const int hoff = h * d, d4 = d >> 2;
+    const long row = (long)b * nq + tok0 + tl;
+    float p[NKB], ds[NKB];
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) p[j] = ds[j] = 0.f;
+    if (act) {
+        const float* qr = q + row * ldq + hoff;
+        const float* dor = dout + row * ldo + hoff;
+        float dp[NKB];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) dp[j] = 0.f;
+        for (int c = 0; c < d4; ++c) {
+            const float4 qv = *reinterpret_cast<const float4*>(qr + c * 4);
+            const float4 gv = *reinterpret_cast<const float4*>(dor + c * 4);
+#pragma unroll
+            for (int j = 0; j < NKB; ++j)
+                if (j < nk) {
+                    const float4 kv = *reinterpret_cast<const float4*>(s_k + j * inner + hoff + c * 4);
+                    const float4 vv = *reinterpret_cast<const float4*>(s_v + j * inner + hoff + c * 4);
+                    p[j] += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+                    dp[j] += gv.x * vv.x + gv.y * vv.y + gv.z * vv.z + gv.w * vv.w;
+                }
+        }
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] *= scale;
+                mx = fmaxf(mx, p[j]);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] = expf(p[j] - mx);
+                sum += p[j];
+            }
+        const float inv = 1.f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] *= inv;
+                dot += p[j] * dp[j];
+            }
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) ds[j] = p[j] * (dp[j] - dot) * scale;  // d(score before scaling) incl. the scale factor
+        // dq = sum_j ds_j k_j
+        for (int c = 0; c < d4; ++c) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NKB; ++j)
+                if (j < nk) {
+                    const float4 kv = *reinterpret_cast<const float4*>(s_k + j * inner + hoff + c * 4);
+                    o.x += ds[j] * kv.x; o.y += ds[j] * kv.y; o.z += ds[j] * kv.z; o.w += ds[j] * kv.w;
+                }
+            *reinterpret_cast<float4*>(dq + row * lddq + hoff + c * 4) = o;
+        }
+    }
+    // dK_j = sum_tokens ds_j q ; dV_j = sum_tokens p_j dO : one key at a time through s_red
+    float* outp = dkv_part + (((long)b * gridDim.x + blockIdx.x) * 2) * nk * inner;
+    for (int which = 0; which < 2; ++which) {
+        for (int j = 0; j < nk; ++j) {
+            __syncthreads();
+            if (act) {
+                const float w = which == 0 ? ds[j] : p[j];
+                const float* src = (which == 0 ? q + row * ldq : dout + row * ldo) + hoff;
+                for (int c = 0; c < d4; ++c) {
+                    const float4 sv = *reinterpret_cast<const float4*>(src + c * 4);
+                    *reinterpret_cast<float4*>(s_red + tl * pitch + hoff + c * 4) =
+                        make_float4(w * sv.x, w * sv.y, w * sv.z, w * sv.w);
+                }
+            }
+            __syncthreads();
+            for (int col = tid; col < inner; col += 256) {
+                float acc = 0.f;
+                for (int t = 0; t < ntok; ++t) acc += s_red[t * pitch + col];
+                outp[((long)which * nk + j) * inner + col] = acc;
+            }
+        }
+    }
+}
+
+__global__ void geglu_fwd_kernel(const float* __restrict__ u, int ld, long rows, int inner, wd_bf16* __restrict__ out_hi,
+                                 wd_bf16* __restrict__ out_lo, int out_ld) {
+    const int i4 = inner >> 2;
+    const long total = rows * i4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / i4;
+        const int c = (int)(i - r * i4) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(u + r * ld + c);
+        const float4 g = *reinterpret_cast<const float4*>(u + r * ld + inner + c);
+        float4 o;
+        o.x = a.x * wd_gelu_erf(g.x); o.y = a.y * wd_gelu_erf(g.y); o.z = a.z * wd_gelu_erf(g.z); o.w = a.w * wd_gelu_erf(g.w);
+        uint2 h, l;
+        wd_split4(o, h, l);
+        *reinterpret_cast<uint2*>(out_hi + r * out_ld + c) = h;
+        if (out_lo) *reinterpret_cast<uint2*>(out_lo + r * out_ld + c) = l;
+    }
+}
+__global__ void geglu_bwd_kernel(const float* __restrict__ u, int ld, const float* __restrict__ dh, int dh_ld, long rows,
+                                 int inner, float* __restrict__ du, int du_ld) {
+    const long total = rows * inner;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / inner;
+        const int c = (int)(i - r * inner);
+        const float a = u[r * ld + c], g = u[r * ld + inner + c], d = dh[r * dh_ld + c];
+        du[r * du_ld + c] = d * wd_gelu_erf(g);
+        du[r * du_ld + inner + c] = d * a * gelu_grad(g);
+    }
+}
+// dpre = dact * silu'(pre)   (time-embedding MLP: the saved tensors are SiLU outputs' pre-activations)
+__global__ void silu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dact, long n,
+                                float* __restrict__ dpre) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dpre[i] = dact[i] * silu_grad(pre[i]);
+}
+// nearest-x2 upsample backward: out[b][y][x][c] = sum of the 2x2 block of in[b][2y..][2x..][c]
+__global__ void pool2x2_sum_kernel(const float* __restrict__ in, int batch, int h, int w, int c, float* __restrict__ out) {
+    const int c4 = c >> 2;
+    const long total = (long)batch * h * w * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4) * 4;
+        const long t = i / c4;
+        const int x = (int)(t % w), y = (int)((t / w) % h), b = (int)(t / ((long)w * h));
+        const long base = (((long)b * 2 * h + 2 * y) * 2 * w + 2 * x) * c + cx;
+        const float4 a0 = *reinterpret_cast<const float4*>(in + base);
+        const float4 a1 = *reinterpret_cast<const float4*>(in + base + c);
+        const float4 a2 = *reinterpret_cast<const float4*>(in + base + (long)2 * w * c);
+        const float4 a3 = *reinterpret_cast<const float4*>(in + base + (long)2 * w * c + c);
+        *reinterpret_cast<float4*>(out + t * c + cx) = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                                                  (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    }
+}
+// embedding backward: dtable[v][c] (+)= sum over rows r with ids[r] == v of d[r][c]  (one thread per table element)
+__global__ void embedding_bwd_kernel(const void* __restrict__ ids, int i64, int rows, const float* __restrict__ d, int ld,
+                                     int vocab, int c, float* __restrict__ dtable, int accumulate) {
+    const long total = (long)vocab * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int vv = (int)(i / c), col = (int)(i - (long)vv * c);
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const long id = i64 ? (long)reinterpret_cast<const int64_t*>(ids)[r] : (long)reinterpret_cast<const int32_t*>(ids)[r];
+            if (id == vv) acc += d[(long)r * ld + col];
+        }
+        dtable[i] = accumulate ? dtable[i] + acc : acc;
+    }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 4096) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace
+
+extern "C" int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int ld, int c, const int32_t* gather,
+                                   int ntaps, int hw_out, int hw_src, int m, int mpad, wd_bf16* out_hi, wd_bf16* out_lo,
+                                   void* stream) {
+    if (!in_hi || !out_hi || c <= 0 || m <= 0 || mpad < m || ntaps < 1 || (gather && (hw_out <= 0 || hw_src <= 0)))
+        return WD_EINVAL;
+    if (!gather && ntaps != 1) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    const dim3 grid((mpad + 63) / 64, (c + 63) / 64, ntaps);
+    if (in_is_f32)
+        hipLaunchKernelGGL(transpose_planes_kernel<true>, grid, dim3(256), 0, st, in_hi, in_lo, ld, c, gather, ntaps, hw_out,
+                           hw_src, m, mpad, out_hi, out_lo);
+    else
+        hipLaunchKernelGGL(transpose_planes_kernel<false>, grid, dim3(256), 0, st, in_hi, in_lo, ld, c, gather, ntaps, hw_out,
+                           hw_src, m, mpad, out_hi, out_lo);
+    return wd_check_launch();
+}
+
+extern "C" int wd_colsum(const float* x, int ld, int rows, int c, int seg, float* out, int out_ld, int accumulate, float scale,
+                         float* scratch, int64_t scratch_floats, void* stream) {
+    if (!x || !out || !scratch || rows <= 0 || c <= 0 || seg <= 0) return WD_EINVAL;
+    const int nseg = (rows + seg - 1) / seg, nblk = (seg + CS_ROWS - 1) / CS_ROWS;
+    if ((int64_t)nseg * nblk * c > scratch_floats) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(colsum_stage1, dim3(nblk, nseg, (c + 255) / 256), dim3(256), 0, st, x, ld, rows, c, seg, scratch);
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 255) / 256, nseg), dim3(256), 0, st, scratch, nblk, c, nseg, out, out_ld,
+                       accumulate, scale);
+    return wd_check_launch();
+}
+
+extern "C" int wd_gn_bwd_nchunk(int hw) { return (hw + GB_TOK - 1) / GB_TOK; }
+
+extern "C" int wd_gn_bwd_stats(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c,
+                               int cpg, const double* part, int nchunk_f, int part_cpg, const float* gamma,
+                               const float* beta, int c_off, float eps, int silu, float* sums, void* stream) {
+    if (!x || !dz || !part || !gamma || !beta || !sums || batch <= 0 || hw <= 0 || c <= 0 || cpg <= 0) return WD_EINVAL;
+    if (c % 4 || ld % 4 || dz_ld % 4 || dz_off % 4 || c_off % 4 || c % cpg || c / cpg > 32 || cpg % part_cpg) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nchunk = wd_gn_bwd_nchunk(hw);
+    const int bx = 64 * ((c / 4 + 63) / 64);
+    if (bx * 2 > 1024) return WD_EINVAL;
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunk, batch), dim3(bx, 2), (64 + 4 * c) * sizeof(float), st, x, ld, dz,
+                       dz_ld, dz_off, hw, c, cpg, part, nchunk_f, part_cpg, gamma, beta, c_off, eps, silu, nchunk, sums);
+    return wd_check_launch();
+}
+
+extern "C" int wd_gn_bwd_apply(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c,
+                               int cpg, const double* part, int nchunk_f, int part_cpg, const float* gamma,
+                               const float* beta, int c_off, float eps, int silu, const float* sums, float* dx, int dx_ld,
+                               int accumulate, void* stream) {
+    if (!x || !dz || !part || !gamma || !beta || !sums || !dx || batch <= 0 || hw <= 0) return WD_EINVAL;
+    if (c % 4 || ld % 4 || dz_ld % 4 || dz_off % 4 || dx_ld % 4 || c_off % 4 || c % cpg || c / cpg > 32 || cpg % part_cpg)
+        return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((hw + GA_TOK - 1) / GA_TOK, batch), dim3(256), 0, st, x, ld, dz, dz_ld,
+                       dz_off, hw, c, cpg, part, nchunk_f, part_cpg, gamma, beta, c_off, eps, silu, sums, wd_gn_bwd_nchunk(hw),
+                       dx, dx_ld, accumulate);
+    return wd_check_launch();
+}
+
+extern "C" int wd_layernorm_bwd_nblk(int rows) { return (rows + LB_ROWS - 1) / LB_ROWS; }
+
+extern "C" int wd_layernorm_bwd(const float* x, int ld, const float* dy, int dy_ld, int rows, int c, const float* gamma,
+                                float eps, float* dx, int dx_ld, int accumulate, float* colpart, void* stream) {
+    if (!x || !dy || !gamma || !dx || !colpart || rows <= 0 || c <= 0) return WD_EINVAL;
+    if (c % 4 || ld % 4 || dy_ld % 4 || dx_ld % 4 || c > 64 * 4 * LB_MAX4) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(wd_layernorm_bwd_nblk(rows)), dim3(256), 4 * c * 2 * sizeof(float), st, x,
+                       ld, dy, dy_ld, rows, c, gamma, eps, dx, dx_ld, accumulate, colpart);
+    return wd_check_launch();
+}
+
+static int attn_bwd_tpw(int heads, int nq, int nk, int d) {
+    const int inner = heads * d;
+    int tpw = 256 / heads;
+    const long budget = (long)150 * 1024 / 4 - (long)2 * nk * inner;
+    if (budget <= 0) return 0;
+    const long fit = budget / (inner + 4);
+    if (fit < tpw) tpw = (int)fit;
+    if (nq < tpw) tpw = nq;
+    return tpw;
+}
+
+extern "C" int wd_attention_bwd_small_nwg(int heads, int nq, int nk, int d) {
+    if (heads <= 0 || heads > 256 || nq <= 0 || nk <= 0 || d <= 0) return 0;
+    const int tpw = attn_bwd_tpw(heads, nq, nk, d);
+    return tpw > 0 ? (nq + tpw - 1) / tpw : 0;
+}
+
+extern "C" int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                      const float* dout, int ldo, int batch, int heads, int nq, int nk, int d, float scale,
+                                      float* dq, int lddq, float* dkv_part, int* nwg_out, void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dkv_part) return WD_EINVAL;
+    if (batch <= 0 || heads <= 0 || heads > 256 || nq <= 0 || nk <= 0 || nk > NKB || d <= 0 || d % 4) return WD_EINVAL;
+    if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddq % 4) return WD_EINVAL;
+    const int inner = heads * d, tpw = attn_bwd_tpw(heads, nq, nk, d);
+    if (tpw <= 0) return WD_EINVAL;
+    const size_t smem = ((size_t)2 * nk * inner + (size_t)tpw * (inner + 4)) * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static size_t set = 64 * 1024;
+    if (smem > set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return WD_ELAUNCH;
+        set = smem;
+    }
+    const int nwg = (nq + tpw - 1) / tpw;
+    if (nwg_out) *nwg_out = nwg;
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(nwg, batch), dim3(256), smem, st, q, ldq, k, ldk, v, ldv, dout, ldo, heads,
+                       nq, nk, d, scale, dq, lddq, dkv_part, tpw);
+    return wd_check_launch();
+}
+
+extern "C" int wd_geglu_fwd(const float* u, int ld, int64_t rows, int inner, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld,
+                            void* stream) {
+    if (!u || !out_hi || rows <= 0 || inner <= 0 || inner % 4 || ld % 4 || out_ld % 4) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * (inner / 4))), dim3(256), 0, st, u, ld, (long)rows, inner,
+                       out_hi, out_lo, out_ld);
+    return wd_check_launch();
+}
+extern "C" int wd_geglu_bwd(const float* u, int ld, const float* dh, int dh_ld, int64_t rows, int inner, float* du, int du_ld,
+                            void* stream) {
+    if (!u || !dh || !du || rows <= 0 || inner <= 0) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * inner)), dim3(256), 0, st, u, ld, dh, dh_ld, (long)rows, inner,
+                       du, du_ld);
+    return wd_check_launch();
+}
+extern "C" int wd_silu_bwd(const float* pre, const float* dact, int64_t n, float* dpre, void* stream) {
+    if (!pre || !dact || !dpre || n <= 0) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, pre, dact, (long)n, dpre);
+    return wd_check_launch();
+}
+extern "C" int wd_pool2x2_sum(const float* in, int batch, int h, int w, int c, float* out, void* stream) {
+    if (!in || !out || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(pool2x2_sum_kernel, dim3(grid_for((long)batch * h * w * (c / 4))), dim3(256), 0, st, in, batch, h, w, c,
+                       out);
+    return wd_check_launch();
+}
+extern "C" int wd_embedding_bwd(const void* ids, int ids_are_i64, int rows, const float* d, int ld, int vocab, int c,
+                                float* dtable, int accumulate, void* stream) {
+    if (!ids || !d || !dtable || rows <= 0 || vocab <= 0 || c <= 0) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for((long)vocab * c)), dim3(256), 0, st, ids, ids_are_i64, rows, d, ld,
+                       vocab, c, dtable, accumulate);
+    return wd_check_launch();
+}
