@@ -196,11 +196,13 @@ int wd_mse_loss(const float* pred, const float* target, int64_t n, float* grad, 
  *  d(input)  = wd_gemm over d(output) planes with the mirrored gather table and transposed weights;
  *  d(weight) = wd_gemm over the token dimension, operands = the transposed planes made by wd_transpose_planes. */
 
-/* out[(t*c + ch)][mm] = in[src(mm, t)][ch] for mm < m (0 beyond, up to mpad): split-bf16 planes [ntaps*c][mpad].
+/* out[(t*c + ch)][mm] (tap_minor = 0) or out[(ch*ntaps + t)][mm] (tap_minor = 1: the OIHW order of a conv weight)
+ *   = in[src(mm, t)][ch] for mm < m (0 beyond, up to mpad): split-bf16 planes [ntaps*c][mpad].
  * in: planes (in_is_f32 = 0; in_lo may be NULL) or one fp32 matrix (in_is_f32 = 1, split on the fly); src = row mm, or
  * through the 3x3 gather table as in wd_gemm (zero row for -1). */
 int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int ld, int c, const int32_t* gather, int ntaps,
-                        int hw_out, int hw_src, int m, int mpad, wd_bf16* out_hi, wd_bf16* out_lo, void* stream);
+                        int hw_out, int hw_src, int m, int mpad, int tap_minor, wd_bf16* out_hi, wd_bf16* out_lo,
+                        void* stream);
 
 /* out[s][col] (+)= scale * sum over rows [s*seg, (s+1)*seg) of x[row][col]; fixed summation order.
  * scratch: ceil(rows/seg) * ceil(seg/64) * c floats.  (bias gradients: seg = rows; FiLM gradient: seg = hw.) */
@@ -233,6 +235,13 @@ int wd_attention_bwd_small_nwg(int heads, int nq, int nk, int d);
 int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout,
                            int ldo, int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq,
                            float* dkv_part, int* nwg_out, void* stream);
+
+/* dst[i] += src[i] (gradient accumulation where a feature map has several consumers: residual adds, the skip stack
+ * of unet.py:1750). 16-byte aligned pointers. */
+int wd_add(float* dst, const float* src, int64_t n, void* stream);
+
+/* packed weight gradient [n][tap*c + ch] (row pitch ld >= ntaps*c) -> the parameter's OIHW order [n][ch][tap]. */
+int wd_permute_dw(const float* packed, int ld, int n, int c, int ntaps, float* out, void* stream);
 
 /* GEGLU unfused (training keeps the pre-activation u = [a | g]): h = a * gelu_erf(g) -> planes; du from dh. */
 int wd_geglu_fwd(const float* u, int ld, int64_t rows, int inner, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);

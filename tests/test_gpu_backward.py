@@ -16,14 +16,14 @@ from worddiffusion_amd.backward import conv_bwd_table, pack_dx_weight, unpack_dw
 from worddiffusion_amd.engine import conv_gather_table  # noqa: E402
 
 
-def transpose_planes(lib, src, is_f32, c, m, mpad, gather=None, ntaps=1, hw_out=0, hw_src=0):
+def transpose_planes(lib, src, is_f32, c, m, mpad, gather=None, ntaps=1, hw_out=0, hw_src=0, tap_minor=0):
     out = torch.zeros(2, ntaps * c, mpad, dtype=torch.bfloat16, device=DEV)
     if is_f32:
         hi, lo, ld = src.data_ptr(), None, src.shape[1]
     else:
         hi, lo, ld = src[0].data_ptr(), src[1].data_ptr(), src.shape[2]
     N.check(lib.wd_transpose_planes(hi, lo, int(is_f32), ld, c, gather.data_ptr() if gather is not None else None, ntaps,
-                                    hw_out, hw_src, m, mpad, out[0].data_ptr(), out[1].data_ptr(), _st()), "transpose")
+                                    hw_out, hw_src, m, mpad, tap_minor, out[0].data_ptr(), out[1].data_ptr(), _st()), "transpose")
     return out
 
 
@@ -51,7 +51,7 @@ def test_conv_data_and_weight_gradients_through_wd_gemm(mode, B, Ci, h, w, Co):
     mpad = (m_out + 63) // 64 * 64
     dyT = transpose_planes(lib, dy_tok.to(DEV), True, Co, m_out, mpad)
     xcolT = transpose_planes(lib, planes_of(x_tok.to(DEV)), False, Ci, m_out, mpad, torch.from_numpy(ftab).to(DEV), 9, hw_out,
-                             hw_in)
+                             hw_in, tap_minor=1)
     args = N.WdGemmArgs()
     s0 = N.WdSrc()
     s0.hi, s0.lo, s0.ld, s0.c, s0.ntaps = dyT[0].data_ptr(), dyT[1].data_ptr(), mpad, mpad, 1
@@ -65,7 +65,15 @@ def test_conv_data_and_weight_gradients_through_wd_gemm(mode, B, Ci, h, w, Co):
     args.ksplit, args.ws, args.ws_floats = 0, ws.data_ptr(), ws.numel()
     N.check(lib.wd_gemm(C.byref(args), _st()), "dW gemm")
     torch.cuda.synchronize()
-    assert rel_err(unpack_dw(dwp.cpu(), wt.shape), wt.grad) < 2e-5
+    assert rel_err(dwp.cpu().reshape(wt.shape), wt.grad) < 2e-5  # tap-minor rows: the GEMM output IS the OIHW gradient
+    packed = torch.randn(Co, 9 * Ci + 4, device=DEV)
+    perm = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    N.check(lib.wd_permute_dw(packed.data_ptr(), 9 * Ci + 4, Co, Ci, 9, perm.data_ptr(), _st()), "permute")
+    acc = perm.clone()
+    N.check(lib.wd_add(acc.data_ptr(), perm.data_ptr(), acc.numel(), _st()), "add")
+    torch.cuda.synchronize()
+    assert torch.equal(perm.cpu(), unpack_dw(packed.cpu()[:, :9 * Ci], wt.shape).float())
+    assert torch.equal(acc, 2 * perm)
 
 
 def test_transpose_planes_and_colsum():
@@ -181,7 +189,7 @@ def test_attention_backward_small(B, H, nq, nk, d, scale):
     dq = torch.zeros(B * nq, inner, device=DEV)
     nwg = lib.wd_attention_bwd_small_nwg(H, nq, nk, d)
     assert nwg > 0
-    part = torch.zeros(B, nwg, 2, nk, inner, device=DEV)
+    part = torch.zeros(B, nwg, nk, 2, inner, device=DEV)
     nw = C.c_int(0)
     N.check(lib.wd_attention_bwd_small(qd.data_ptr(), inner, kd.data_ptr(), inner, vd.data_ptr(), inner, dod.data_ptr(), inner,
                                        B, H, nq, nk, d, scale, dq.data_ptr(), inner, part.data_ptr(), C.byref(nw), _st()),
@@ -190,8 +198,8 @@ def test_attention_backward_small(B, H, nq, nk, d, scale):
     assert nw.value == nwg
     assert max_rel(dq.cpu(), qr.grad) < 3e-5
     dkv = part.sum(1).cpu()
-    assert max_rel(dkv[:, 0].reshape(B * nk, inner), kr.grad) < 3e-5
-    assert max_rel(dkv[:, 1].reshape(B * nk, inner), vr.grad) < 3e-5
+    assert max_rel(dkv[:, :, 0].reshape(B * nk, inner), kr.grad) < 3e-5
+    assert max_rel(dkv[:, :, 1].reshape(B * nk, inner), vr.grad) < 3e-5
 
 
 def test_geglu_silu_pool_embedding_backward():

@@ -245,3 +245,68 @@ def test_optimizer_side_of_train_step(golden_dir):
         assert max_rel(p.detach().cpu(), c.detach()) < 1e-6
         ref_e = b.cpu() * 0.995 + (1 - 0.995) * p.detach().cpu()
         assert max_rel(e.detach().cpu(), ref_e) < 1e-6
+
+
+def _oracle_train_reference(cfg, seed, inp, eps):
+    """Oracle forward + autograd on the CPU (fp32): loss, prediction and every parameter gradient."""
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    shapes = U.state_dict_shapes(cfg, "base")
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, seed)).requires_grad_(True) for k, s in shapes}
+    # zero-initialised convolutions (out, proj_out, out_layers.3) would silence most of the backward: they are filled too
+    orc = U.UNetOracle(cfg, sd, "base", False)
+    pred = orc(inp["x"], inp["t"], inp["context"], inp["y"])
+    loss = torch.nn.functional.mse_loss(pred, eps)
+    loss.backward()
+    return sd, pred.detach(), loss.detach()
+
+
+@pytest.mark.parametrize("cfg_name,B,hw", [("SMALL", 4, (4, 8)), ("DEEP", 3, (8, 16)), ("SMALL", 2, (8, 32)), ("FULL", 2, (8, 32))])
+def test_training_step_gradients_match_oracle_autograd(cfg_name, B, hw):
+    """model(...) in train mode -> MSELoss -> loss.backward() (train.py:287-291) on the HIP path vs the oracle under torch
+    autograd: loss, prediction and EVERY parameter gradient (and the same set of parameters left without a gradient)."""
+    cfg = {"SMALL": SMALL, "DEEP": DEEP, "FULL": FULL}[cfg_name]
+    seed = 77
+    inp = synthetic_inputs(B, seed=43, hw=hw, num_classes=cfg["num_classes"])
+    eps = torch.from_numpy(np.random.RandomState(44).standard_normal(tuple(inp["x"].shape)).astype(np.float32))
+    sd, pred_ref, loss_ref = _oracle_train_reference(cfg, seed, inp, eps)
+    m = UNetModel(args=make_args(), **cfg)
+    fill_module_(m, seed)
+    m = m.to(DEV).train()
+    pred = m(inp["x"].to(DEV), timesteps=inp["t"].to(DEV), context=inp["context"].to(DEV), y=inp["y"].to(DEV))
+    assert pred.requires_grad
+    loss = torch.nn.MSELoss()(eps.to(DEV), pred)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert max_rel(pred.detach().cpu(), pred_ref) < 5e-5
+    assert abs(float(loss.detach()) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+    params = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for k, ref in sd.items():
+        g = params[k].grad
+        if ref.grad is None:
+            assert g is None, f"{k}: the reference leaves this parameter without a gradient"
+            continue
+        assert g is not None, f"{k}: missing gradient"
+        assert tuple(g.shape) == tuple(ref.grad.shape), k
+        r = ref.grad.double()
+        err = float((g.detach().cpu().double() - r).norm())
+        tol = 2e-4 * float(r.norm()) + 1e-7  # (a few gradients are analytically ~0: absolute floor)
+        if err / (float(r.norm()) + 1e-30) > worst[1] and float(r.norm()) > 1e-6:
+            worst = (k, err / float(r.norm()))
+        assert err < tol, (k, err, float(r.norm()))
+    print("worst relative gradient error:", worst)
+    # a second backward after zero_grad reproduces the gradients bit for bit (deterministic reductions)
+    g1 = {k: p.grad.clone() for k, p in params.items() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    pred2 = m(inp["x"].to(DEV), timesteps=inp["t"].to(DEV), context=inp["context"].to(DEV), y=inp["y"].to(DEV))
+    torch.nn.MSELoss()(eps.to(DEV), pred2).backward()
+    torch.cuda.synchronize()
+    for k, g in g1.items():
+        assert torch.equal(params[k].grad, g), k
+    # keeping .grad (no zero_grad) accumulates like autograd
+    pred3 = m(inp["x"].to(DEV), timesteps=inp["t"].to(DEV), context=inp["context"].to(DEV), y=inp["y"].to(DEV))
+    torch.nn.MSELoss()(eps.to(DEV), pred3).backward()
+    torch.cuda.synchronize()
+    k0 = "input_blocks.1.0.in_layers.2.weight"
+    assert max_rel(params[k0].grad, 2 * g1[k0]) < 1e-6

@@ -63,7 +63,9 @@ _SIGS = {
     "wd_adamw_multi": (_i, [_vp, _i, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, _i,
                            C.c_double, _vp]),
     "wd_mse_loss": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _i, _vp]),
-    "wd_transpose_planes": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wd_transpose_planes": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wd_add": (_i, [_vp, _vp, C.c_int64, _vp]),
+    "wd_permute_dw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wd_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, C.c_int64, _vp]),
     "wd_gn_bwd_nchunk": (_i, [_i]),
     "wd_gn_bwd_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp]),

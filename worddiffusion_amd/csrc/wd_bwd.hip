@@ -26,7 +26,7 @@ __device__ __forceinline__ float gelu_grad(float g) {  // d gelu_erf(g) / dg
 template <bool F32IN>
 __global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __restrict__ in_hi, const void* __restrict__ in_lo,
                                                                int ld, int c, const int32_t* __restrict__ gather, int ntaps,
-                                                               int hw_out, int hw_src, int m, int mpad,
+                                                               int hw_out, int hw_src, int m, int mpad, int tap_minor,
                                                                wd_bf16* __restrict__ out_hi, wd_bf16* __restrict__ out_lo) {
     __shared__ wd_bf16 th[64][66], tl[64][66];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __res
     for (int r = ty; r < 64; r += 4) {       // r: channel inside the tile, tx: token
         const int cc = c0 + r, mm = m0 + tx;
         if (cc < c && mm < mpad) {
-            const long o = ((long)tap * c + cc) * mpad + mm;
+            const long o = (tap_minor ? (long)cc * ntaps + tap : (long)tap * c + cc) * mpad + mm;
             out_hi[o] = th[tx][r];
             if (out_lo) out_lo[o] = tl[tx][r];
         }
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 }
 
 // ---- attention backward, few keys: thread = (token, head); dq written per token; dK / dV reduced over the
-// workgroup's tokens through LDS in fixed order and written as per-workgroup partials [b][nwg][2][nk][inner]
+// workgroup's tokens through LDS in fixed order and written as per-workgroup partials [b][nwg][nk][2][inner]
 constexpr int NKB = 16;
 __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                              int ldk, const float* __restrict__ v, int ldv,
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __rest
             for (int col = tid; col < inner; col += 256) {
                 float acc = 0.f;
                 for (int t = 0; t < ntok; ++t) acc += s_red[t * pitch + col];
-                outp[((long)which * nk + j) * inner + col] = acc;
+                outp[((long)j * 2 + which) * inner + col] = acc;
             }
         }
     }
@@ -493,6 +493,25 @@ __global__ void embedding_bwd_kernel(const void* __restrict__ ids, int i64, int 
     }
 }
 
+// dst[i] += src[i]
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(dst)[i];
+        const float4 b = reinterpret_cast<const float4*>(src)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(dst)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] += src[n4 * 4 + threadIdx.x];
+}
+// packed weight gradient [n][tap * c + ch] (row pitch ld) -> OIHW [n][ch][tap]
+__global__ void permute_dw_kernel(const float* __restrict__ packed, int ld, int n, int c, int ntaps, float* __restrict__ out) {
+    const long total = (long)n * c * ntaps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ntaps), ch = (int)((i / ntaps) % c), r = (int)(i / ((long)ntaps * c));
+        out[i] = packed[(long)r * ld + t * c + ch];
+    }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 4096) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -502,8 +521,8 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 }  // namespace
 
 extern "C" int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int ld, int c, const int32_t* gather,
-                                   int ntaps, int hw_out, int hw_src, int m, int mpad, wd_bf16* out_hi, wd_bf16* out_lo,
-                                   void* stream) {
+                                   int ntaps, int hw_out, int hw_src, int m, int mpad, int tap_minor, wd_bf16* out_hi,
+                                   wd_bf16* out_lo, void* stream) {
     if (!in_hi || !out_hi || c <= 0 || m <= 0 || mpad < m || ntaps < 1 || (gather && (hw_out <= 0 || hw_src <= 0)))
         return WD_EINVAL;
     if (!gather && ntaps != 1) return WD_EINVAL;
@@ -512,10 +531,10 @@ extern "C" int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_
     const dim3 grid((mpad + 63) / 64, (c + 63) / 64, ntaps);
     if (in_is_f32)
         hipLaunchKernelGGL(transpose_planes_kernel<true>, grid, dim3(256), 0, st, in_hi, in_lo, ld, c, gather, ntaps, hw_out,
-                           hw_src, m, mpad, out_hi, out_lo);
+                           hw_src, m, mpad, tap_minor, out_hi, out_lo);
     else
         hipLaunchKernelGGL(transpose_planes_kernel<false>, grid, dim3(256), 0, st, in_hi, in_lo, ld, c, gather, ntaps, hw_out,
-                           hw_src, m, mpad, out_hi, out_lo);
+                           hw_src, m, mpad, tap_minor, out_hi, out_lo);
     return wd_check_launch();
 }
 
@@ -659,5 +678,21 @@ extern "C" int wd_embedding_bwd(const void* ids, int ids_are_i64, int rows, cons
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for((long)vocab * c)), dim3(256), 0, st, ids, ids_are_i64, rows, d, ld,
                        vocab, c, dtable, accumulate);
+    return wd_check_launch();
+}
+
+extern "C" int wd_add(float* dst, const float* src, int64_t n, void* stream) {
+    if (!dst || !src || n <= 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, dst, src, (long)(n / 4), (long)n);
+    return wd_check_launch();
+}
+
+extern "C" int wd_permute_dw(const float* packed, int ld, int n, int c, int ntaps, float* out, void* stream) {
+    if (!packed || !out || n <= 0 || c <= 0 || ntaps <= 0 || ld < c * ntaps) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(permute_dw_kernel, dim3(grid_for((long)n * c * ntaps)), dim3(256), 0, st, packed, ld, n, c, ntaps, out);
     return wd_check_launch();
 }

@@ -128,6 +128,7 @@ class UNetBase(nn.Module):
                                  _zero(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
         self._extra_heads_after_out()
         self._engine = None
+        self._train_engine = None
         dev = _arg(args, "device", None)
         if dev is not None and str(dev) != "cpu":
             # the reference moves word_emb to args.device in the constructor (unet.py:1210-1213); callers then
@@ -158,7 +159,7 @@ class UNetBase(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_train_engine", "_anchor") else copy.deepcopy(v, memo)
         return new
 
     def set_precision(self, mode: str):
@@ -173,10 +174,6 @@ class UNetBase(nn.Module):
         pass
 
     def _check_common(self, x, timesteps, mix_rate):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError(
-                "the HIP path implements the inference forward (sampling); call under torch.no_grad() / .eval(). "
-                "Backward kernels for the training step are the next row of the plan (DESIGN.md)")
         if self.interpolation and mix_rate is not None:
             raise NotImplementedError("writer-style interpolation (mix_rate) draws two random writers on the host "
                                       "(unet.py:1558-1573); not on the accelerated path")
@@ -185,6 +182,49 @@ class UNetBase(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"x must be [B,{self.in_channels},H,W], got {tuple(x.shape)}")
 
+    @property
+    def train_engine(self):
+        """Forward-with-saved-intermediates + backward launch lists (``train_engine.py``); base variant only."""
+        if self._train_engine is None:
+            from .train_engine import TrainEngine
+            self._train_engine = TrainEngine(self, self.variant)
+            mode = os.environ.get("WDIFF_PRECISION")
+            if mode:
+                self._train_engine.set_precision(mode)
+        return self._train_engine
+
     def _run(self, x, timesteps, context, y, phosc=None):
+        if torch.is_grad_enabled() and self.training:
+            # ``predicted_noise = model(...)`` inside the training loop (train.py:287): the result carries a grad_fn whose
+            # backward runs the HIP backward list and fills ``param.grad`` (reference layouts), so ``loss.backward()``,
+            # ``optimizer.step()`` and ``ema.step_ema`` of the reference loop work unchanged.
+            if phosc is not None:
+                raise NotImplementedError("PHOSC-conditioned training step (next row, DESIGN.md)")
+            return _HipUNetStep.apply(self, x, timesteps, context, y, self._grad_anchor(x.device)).type(x.dtype)
         out = self.engine.forward(x.float(), timesteps, context, y, phosc)
         return out.type(x.dtype)
+
+    def _grad_anchor(self, device):
+        a = self.__dict__.get("_anchor")
+        if a is None or a.device != device:
+            a = torch.zeros(1, device=device, requires_grad=True)
+            self.__dict__["_anchor"] = a
+        return a
+
+
+class _HipUNetStep(torch.autograd.Function):
+    """Autograd node of the HIP training forward.  The parameters are not inputs of the node: their gradients are written
+    by the backward kernels into persistent buffers that become ``param.grad`` (added to an existing ``.grad``, as autograd
+    would).  ``anchor`` is a dummy leaf that makes autograd schedule the node; x / context get no gradient (train.py never
+    asks for one)."""
+
+    @staticmethod
+    def forward(ctx, model, x, timesteps, context, y, anchor):
+        eng = model.train_engine
+        ctx.eng = eng
+        return eng.forward_train(x.float(), timesteps, context, y).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.eng.backward(gout.contiguous().float())
+        return None, None, None, None, None, torch.zeros_like(ctx.eng.model._anchor)

@@ -1,0 +1,816 @@
+"""Training-step engine: the forward of ``engine.py`` with every intermediate kept, plus a hand-scheduled backward.
+
+The reference trains with autograd over ~150 ATen modules (``train.py:287-293``: ``model(...)`` -> ``MSELoss`` ->
+``loss.backward()``).  Here the backward is a static launch list, built once per input shape next to the forward list:
+
+  * d(input) of every convolution / linear is ``wd_gemm`` again - over the planes of d(output), with the inverse gather
+    table (``backward.conv_bwd_table``) and the weights repacked [C_in][tap][C_out] ("B:" entries of the weight cache);
+  * d(weight) is ``wd_gemm`` with the token dimension as the reduction: both operands are transposed into split-bf16
+    planes by ``wd_transpose_planes`` (rows ordered (c_in, tap), so the GEMM output IS the OIHW gradient) and the kernel's
+    split-K spreads the long reduction over the chip;
+  * GroupNorm(+SiLU), LayerNorm, attention over the <=16 context tokens, GEGLU, SiLU, nearest-x2 and the embeddings
+    have their own kernels in ``csrc/wd_bwd.hip``; bias / FiLM / norm-parameter gradients are deterministic two-stage
+    column sums (no float atomics anywhere: a replayed step is bit-identical).
+
+Gradients land in persistent buffers that become ``param.grad`` (reference layout), so ``torch.optim.AdamW``, gradient
+clipping, DDP-style all-reduce (``dist.GradAllReducer``) and ``optim.FusedAdamW`` all see what autograd would have given
+them.  Forward + backward replay as one hipGraph.  Scope: the base ``unet.UNetModel`` (what ``train.py:403`` builds).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _native as N
+from .backward import conv_bwd_table, pack_dx_weight
+from .engine import Act, Plan, UNetEngine, _ptr
+from .layers import DownsampleParams, ResBlockParams, SpatialTransformerParams, UpsampleParams
+
+
+class TAct(Act):
+    """Feature map + its gradient buffer (``g``) and whether the backward list has written it yet (``gw``)."""
+    __slots__ = ("g", "gw")
+
+    def __init__(self, t, c, h, w, stats=None):
+        super().__init__(t, c, h, w, stats)
+        self.g, self.gw = None, False
+
+
+class TrainPlan(Plan):
+    def __init__(self):
+        super().__init__()
+        self.bwd: List[tuple] = []
+        self.dout: Optional[torch.Tensor] = None
+
+    def run_bwd(self, stream):
+        self._run(self.bwd, stream)
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class TrainEngine(UNetEngine):
+    def __init__(self, model, variant: str):
+        if variant != "base":
+            raise NotImplementedError("the HIP training step covers unet.UNetModel (train.py:403); the PHOSC variant's "
+                                      "spatial self-attention backward is the next row (DESIGN.md)")
+        super().__init__(model, variant)
+        self._tplans: Dict[tuple, TrainPlan] = {}
+        self._grad: Dict[int, torch.Tensor] = {}     # id(param) -> gradient buffer (possibly a view into a group)
+        self._params: Dict[int, torch.nn.Parameter] = {}
+        self._btabs: Dict[tuple, torch.Tensor] = {}
+        self._scr: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _recipes(self):
+        rec = super()._recipes()
+        m = self.model
+        we = m.word_emb
+        rec["B:we.qkv.w"] = lambda: pack_dx_weight(torch.cat(
+            [we.attention.linear_query.weight, we.attention.linear_key.weight, we.attention.linear_value.weight], 0))
+        film_w, kv_w = [], []
+        for name, mod in self._walk():
+            if isinstance(mod, ResBlockParams):
+                rec["B:" + name + ".c1.w"] = (lambda mod=mod: pack_dx_weight(mod.in_layers[2].weight))
+                rec["B:" + name + ".c2.w"] = (lambda mod=mod: pack_dx_weight(mod.out_layers[3].weight))
+                if mod.cin != mod.cout:
+                    rec["B:" + name + ".skip.w"] = (lambda mod=mod: pack_dx_weight(
+                        mod.skip_connection.weight.reshape(mod.cout, mod.cin)))
+                film_w.append(mod.emb_layers[1])
+            elif isinstance(mod, DownsampleParams):
+                rec["B:" + name + ".w"] = (lambda mod=mod: pack_dx_weight(mod.op.weight))
+            elif isinstance(mod, UpsampleParams):
+                rec["B:" + name + ".w"] = (lambda mod=mod: pack_dx_weight(mod.conv.weight))
+            elif isinstance(mod, SpatialTransformerParams):
+                rec["B:" + name + ".pi.w"] = (lambda mod=mod: pack_dx_weight(mod.proj_in.weight.flatten(1)))
+                rec["B:" + name + ".po.w"] = (lambda mod=mod: pack_dx_weight(mod.proj_out.weight.flatten(1)))
+                for d, tb in enumerate(mod.transformer_blocks):
+                    p = f"{name}.tb{d}"
+                    for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
+                        rec[f"B:{p}.{tag}.q.w"] = (lambda at=at: pack_dx_weight(at.to_q.weight))
+                        rec[f"B:{p}.{tag}.o.w"] = (lambda at=at: pack_dx_weight(at.to_out[0].weight))
+                        kv_w.append(at)
+                    # the training forward keeps the GEGLU pre-activation: plain [x | gate] row order (unet.py:128)
+                    rec[p + ".ff1u.w"] = (lambda tb=tb: tb.ff.net[0].proj.weight)
+                    rec[p + ".ff1u.b"] = (lambda tb=tb: tb.ff.net[0].proj.bias)
+                    rec["B:" + p + ".ff1.w"] = (lambda tb=tb: pack_dx_weight(tb.ff.net[0].proj.weight))
+                    rec["B:" + p + ".ff2.w"] = (lambda tb=tb: pack_dx_weight(tb.ff.net[2].weight))
+        rec["B:film.w"] = lambda: pack_dx_weight(torch.cat([l.weight for l in film_w], 0))
+        rec["B:kv.w"] = lambda: pack_dx_weight(torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in kv_w], 0))
+        rec["B:te2.w"] = lambda: pack_dx_weight(m.time_embed[2].weight)
+
+        def out_bw():  # C_out padded to 32 columns per tap (the gradient planes of a 4-channel map are 32 wide)
+            wt = m.out[2].weight
+            pad = wt.new_zeros(32, *wt.shape[1:])
+            pad[: wt.shape[0]] = wt
+            return pack_dx_weight(pad)
+
+        rec["B:out.w"] = out_bw
+        self._film_mods, self._kv_mods = film_w, kv_w
+        return rec
+
+    # ------------------------------------------------------------------------------------------ gradient buffers
+    def _pgrad(self, p: torch.nn.Parameter) -> torch.Tensor:
+        if id(p) not in self._grad:
+            self._grad[id(p)] = torch.zeros(p.shape, dtype=torch.float32, device=self.device)
+            self._params[id(p)] = p
+        return self._grad[id(p)]
+
+    def _pgroup(self, params: List[torch.nn.Parameter]) -> torch.Tensor:
+        """One buffer whose row blocks are the gradients of ``params`` (weights the forward concatenates: all FiLM
+        projections, every cross-attention's K/V, the word encoder's q/k/v)."""
+        key = ("group",) + tuple(id(p) for p in params)
+        if key not in self._scr:
+            tail = tuple(params[0].shape[1:])
+            rows = sum(p.shape[0] for p in params)
+            buf = torch.zeros((rows,) + tail, dtype=torch.float32, device=self.device)
+            r0 = 0
+            for p in params:
+                self._grad[id(p)] = buf[r0:r0 + p.shape[0]]
+                self._params[id(p)] = p
+                r0 += p.shape[0]
+            self._scr[key] = buf
+        return self._scr[key]
+
+    def _pacc(self, t: torch.Tensor) -> int:
+        """1 if the backward list has already written this parameter-gradient buffer (shared norm2), else 0."""
+        k = t.data_ptr()
+        acc = k in self._pw
+        self._pw.add(k)
+        return int(acc)
+
+    def _gacc(self, P, act: TAct):
+        if act.g is None:
+            act.g = self._f32(P, *act.t.shape)
+        acc = act.gw
+        act.gw = True
+        return act.g, int(acc)
+
+    def _scratch(self, key: str, numel: int, dtype) -> torch.Tensor:
+        cur = self._scr.get(key)
+        if cur is None or cur.numel() < numel:
+            if cur is not None and self._tplans:
+                raise RuntimeError("scratch grew after a plan was built")  # sized by _size_scratch before any use
+            self._scr[key] = torch.zeros(numel, dtype=dtype, device=self.device)
+        return self._scr[key]
+
+    def _btable(self, h, w, mode):
+        key = (h, w, mode)
+        if key not in self._btabs:
+            tab, _, _ = conv_bwd_table(h, w, mode)
+            dt = torch.from_numpy(tab).to(self.device)
+            self._btabs[key] = dt
+            self._tab_np[dt.data_ptr()] = tab
+        return self._btabs[key]
+
+    # ------------------------------------------------------------------------------------------ backward emitters
+    def _colsum(self, ops, what, x_ptr, ld, rows, c, seg, out_ptr, out_ld, acc, scale=1.0):
+        scr = self._cs_scratch
+        nseg, nblk = (rows + seg - 1) // seg, (seg + 63) // 64
+        assert nseg * nblk * c <= scr.numel(), (what, nseg, nblk, c)
+        ops.append((self.lib.wd_colsum, (x_ptr, ld, rows, c, seg, out_ptr, out_ld, int(acc), float(scale), scr.data_ptr(),
+                                         scr.numel()), what))
+
+    def _gemm_dw(self, ops, what, doutT, nrows, xT, ncols, mpad, out: torch.Tensor, out_ld, acc):
+        a = N.WdGemmArgs()
+        s = N.WdSrc()
+        s.hi, s.lo = doutT[0].data_ptr(), doutT[1].data_ptr()
+        s.ld, s.c, s.ntaps, s.hw_src = mpad, mpad, 1, 0
+        a.src[0] = s
+        a.nsrc, a.npass = 1, self.npass
+        a.w_hi, a.w_lo = xT[0].data_ptr(), xT[1].data_ptr()
+        a.m, a.n, a.ktot, a.hw_out = nrows, ncols, mpad, 1
+        a.out_f32, a.out_ld = out.data_ptr(), out_ld
+        if acc:
+            a.resid, a.resid_ld = out.data_ptr(), out_ld
+        a.ksplit, a.ws, a.ws_floats = 0, self._ws.data_ptr(), self._ws.numel()
+        self._cur_plan.keep.append(a)
+        ops.append((self.lib.wd_gemm, (C.byref(a),), what))
+
+    def _bwd_linear(self, P, what, dout: torch.Tensor, M, n, hw_out, segs, bias=(), film_off=None, npad=None):
+        """Backward of out[M, n] = sum_seg gather(planes_seg) . W_seg^T + bias (+ FiLM row vector).
+
+        seg keys: planes [2, rows, ld], c, ntaps, ftab (forward table or None), hw_src (forward source positions per
+        sample), wgrad (tensor [n, c*ntaps] in OIHW order, or None), wgrad_packed (tensor [n, ld_k] for the im2col input
+        conv), wb (name of the data-gradient weight) and dx: list of (tensor, ld, acc, w_row_off, nrows) written by the
+        data-gradient GEMM whose rows are dx_rows output positions (dx_hw per sample) through btab."""
+        ops = P.bwd
+        lib = self.lib
+        npad = n if npad is None else npad
+        ldd = dout.shape[1]
+        mpad = _rup(M, 64)
+        lo_ok = self.npass == 3
+        need_dx = any(s.get("dx") for s in segs)
+        if need_dx:
+            if ldd == npad:
+                dpl = self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)[: 2 * M * npad].view(2, M, npad)
+            else:
+                raise AssertionError(what)
+            ops.append((lib.wd_split, (dout.data_ptr(), ldd, M, npad, 0, dpl[0].data_ptr(),
+                                       dpl[1].data_ptr() if lo_ok else None, npad), what + ":split(dout)"))
+        need_dw = any(s.get("wgrad") is not None or s.get("wgrad_packed") is not None for s in segs)
+        if need_dw:
+            doutT = self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)[: 2 * n * mpad].view(2, n, mpad)
+            ops.append((lib.wd_transpose_planes, (dout.data_ptr(), None, 1, ldd, n, None, 1, 0, 0, M, mpad, 0,
+                                                  doutT[0].data_ptr(), doutT[1].data_ptr()), what + ":T(dout)"))
+        for si, s in enumerate(segs):
+            c, ntaps = s["c"], s["ntaps"]
+            planes = s["planes"]
+            for (dx, dx_ld, acc, roff, nrows) in s.get("dx") or ():
+                src = self._src(dpl, npad, ntaps, s.get("btab"), hw_out if s.get("btab") is not None else 0)
+                self._gemm(ops, f"{what}:dX{si}", [src], s["wb"], s["dx_rows"], s["dx_hw"],
+                           resid=dx.data_ptr() if acc else None, resid_ld=dx_ld if acc else 0, out_f32=dx, out_ld=dx_ld,
+                           n=nrows, w_row_off=roff)
+            wg, wgp = s.get("wgrad"), s.get("wgrad_packed")
+            if wg is None and wgp is None:
+                continue
+            k = ntaps * c
+            xT = self._scratch("xT", 2 * self._max_xT, torch.bfloat16)[: 2 * k * mpad].view(2, k, mpad)
+            ftab = s.get("ftab")
+            ops.append((lib.wd_transpose_planes,
+                        (planes[0].data_ptr() + 2 * s.get("col_off", 0), planes[1].data_ptr() + 2 * s.get("col_off", 0), 0,
+                         planes.shape[2], c, _ptr(ftab), ntaps, hw_out if ftab is not None else 0,
+                         s["hw_src"] if ftab is not None else 0, M, mpad, 1 if wgp is None else 0, xT[0].data_ptr(),
+                         xT[1].data_ptr()), f"{what}:T(x{si})"))
+            if wgp is not None:
+                packed, dst, cin = wgp
+                self._gemm_dw(ops, f"{what}:dW{si}", doutT, n, xT, k, mpad, packed, k, 0)
+                ops.append((lib.wd_permute_dw, (packed.data_ptr(), k, n, cin, 9, dst.data_ptr()), f"{what}:dW{si}:oihw"))
+                self._pacc(dst)
+            else:
+                self._gemm_dw(ops, f"{what}:dW{si}", doutT, n, xT, k, mpad, wg, k, self._pacc(wg))
+        for b in bias:
+            self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
+        if film_off is not None:
+            self._colsum(ops, what + ":dfilm", dout.data_ptr(), ldd, M, n, hw_out,
+                         self._dfilm.data_ptr() + 4 * film_off, self.film_total, 0)
+
+    def _gn_bwd(self, P, what, srcs: List[TAct], gn: torch.nn.GroupNorm, eps, silu, dz: torch.Tensor):
+        ops = P.bwd
+        lib = self.lib
+        B = self._B
+        hw = srcs[0].h * srcs[0].w
+        ctot = sum(s.c for s in srcs)
+        cpg = ctot // 32
+        gam, bet = gn.weight, gn.bias
+        gw, gb = self._w[self._gn_names[id(gn)] + ".g"], self._w[self._gn_names[id(gn)] + ".b"]
+        dgam, dbet = self._pgrad(gam), self._pgrad(bet)
+        nb = lib.wd_gn_bwd_nchunk(hw)
+        off = 0
+        accp = self._pacc(dgam)
+        self._pacc(dbet)
+        for s in srcs:
+            part, nchunk, pc = s.stats
+            sums = self._f32(P, B, nb, 2, s.c)
+            common = (s.t.data_ptr(), s.c, dz.data_ptr(), ctot, off, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc,
+                      gw.data_ptr(), gb.data_ptr(), off, eps, int(silu), sums.data_ptr())
+            ops.append((lib.wd_gn_bwd_stats, common, what + ":stats"))
+            g, acc = self._gacc(P, s)
+            ops.append((lib.wd_gn_bwd_apply, common + (g.data_ptr(), s.c, acc), what + ":apply"))
+            self._colsum(ops, what + ":dbeta", sums.data_ptr(), 2 * s.c, B * nb, s.c, B * nb, dbet.data_ptr() + 4 * off,
+                         s.c, accp)
+            self._colsum(ops, what + ":dgamma", sums.data_ptr() + 4 * s.c, 2 * s.c, B * nb, s.c, B * nb,
+                         dgam.data_ptr() + 4 * off, s.c, accp)
+            off += s.c
+
+    def _ln_bwd(self, P, what, x: torch.Tensor, rows, c, ln: torch.nn.LayerNorm, name, dy: torch.Tensor, dx: torch.Tensor,
+                acc: int):
+        ops = P.bwd
+        lib = self.lib
+        nblk = lib.wd_layernorm_bwd_nblk(rows)
+        colpart = self._f32(P, nblk, 2, c)
+        ops.append((lib.wd_layernorm_bwd, (x.data_ptr(), c, dy.data_ptr(), c, rows, c, self._w[name + ".g"].data_ptr(), 1e-5,
+                                           dx.data_ptr(), c, int(acc), colpart.data_ptr()), what))
+        dg, db = self._pgrad(ln.weight), self._pgrad(ln.bias)
+        accp = self._pacc(dg)
+        self._pacc(db)
+        self._colsum(ops, what + ":dgamma", colpart.data_ptr(), 2 * c, nblk, c, nblk, dg.data_ptr(), c, accp)
+        self._colsum(ops, what + ":dbeta", colpart.data_ptr() + 4 * c, 2 * c, nblk, c, nblk, db.data_ptr(), c, accp)
+
+    def _attn_bwd(self, P, what, q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO: torch.Tensor, heads, nq, nk, d, scale, dq_ptr, lddq,
+                  dkv_ptr, dkv_pitch_floats):
+        """dq -> dq_ptr; [dK | dV] rows (b, j) -> dkv_ptr with the given row pitch (2*inner floats wide)."""
+        ops = P.bwd
+        lib = self.lib
+        B = self._B
+        inner = heads * d
+        nwg = lib.wd_attention_bwd_small_nwg(heads, nq, nk, d)
+        if nwg <= 0 or nk > 16:
+            raise NotImplementedError(f"attention backward for {nk} keys (<= 16 context tokens supported)")
+        part = self._f32(P, B, nwg, nk, 2, inner)
+        ops.append((lib.wd_attention_bwd_small, (q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO.data_ptr(), dO.shape[1], B, heads, nq, nk,
+                                                 d, float(scale), dq_ptr, lddq, part.data_ptr(), None), what))
+        row = nk * 2 * inner
+        tmp = self._f32(P, B, row)
+        self._colsum(ops, what + ":dkv", part.data_ptr(), row, B * nwg, row, nwg, tmp.data_ptr(), row, 0)
+        ops.append((lib.wd_copy2d, (dkv_ptr, 4 * dkv_pitch_floats, tmp.data_ptr(), 8 * inner, 8 * inner, B * nk),
+                    what + ":dkv->slice"))
+
+    # ------------------------------------------------------------------------------------------ blocks (fwd + tape)
+    def _resblock(self, P, name, mod: ResBlockParams, srcs: List[TAct]) -> TAct:
+        ops = P.step
+        B = self._B
+        h, w = srcs[0].h, srcs[0].w
+        hw, M = h * w, B * h * w
+        cin, cout = mod.cin, mod.cout
+        tab, _, _ = self._table(h, w, "same")
+        need_raw = cin != cout
+        if mod.out_layers[2].p != 0:
+            raise NotImplementedError("dropout > 0 in the HIP training step (train.py builds the UNet with dropout 0)")
+        cpg = cin // 32
+        parts = None
+        if any(s.c % cpg for s in srcs):
+            # GroupNorm groups straddle the skip concat (never at 320+320): materialise it (unet.py:1750) and hand its
+            # gradient back to the two halves at the end of the block's backward
+            parts = srcs
+            catt = self._f32(P, M, cin)
+            coff = 0
+            for s in parts:
+                ops.append((self.lib.wd_copy2d, (catt.data_ptr() + 4 * coff, 4 * cin, s.t.data_ptr(), 4 * s.c, 4 * s.c, M),
+                            name + ":concat"))
+                coff += s.c
+            srcs = [TAct(catt, cin, h, w)]
+        a1, raw = self._gn(P, ops, name + ".gn1", srcs, name + ".gn1", 1e-5, True, want_raw=need_raw)
+        h1t = self._f32(P, M, cout)
+        g1 = self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
+                        bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
+                        rowvec_ld=self.film_total, out_f32=h1t, out_ld=cout, want_stats=True)
+        h1 = TAct(h1t, cout, h, w, g1._stats)
+        a2, _ = self._gn(P, ops, name + ".gn2", [h1], name + ".gn2", 1e-5, True)
+        outt = self._f32(P, M, cout)
+        if need_raw:
+            g2 = self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
+                            name + ".c2.w", M, hw, bias=self._w[name + ".c2.b"], out_f32=outt, out_ld=cout,
+                            want_stats=True)
+        else:
+            g2 = self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
+                            bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=outt,
+                            out_ld=cout, want_stats=True)
+        out = TAct(outt, cout, h, w, g2._stats)
+        self._gn_names[id(mod.in_layers[0])] = name + ".gn1"
+        self._gn_names[id(mod.out_layers[0])] = name + ".gn2"
+
+        def bwd():
+            bops = P.bwd
+            assert out.gw, name
+            dO = out.g
+            btab = self._btable(h, w, "same")
+            da2 = self._f32(P, M, cout)
+            segs = [dict(planes=a2, c=cout, ntaps=9, ftab=tab, btab=btab, hw_src=hw, wb="B:" + name + ".c2.w",
+                         wgrad=self._pgrad(mod.out_layers[3].weight).view(cout, -1), dx=[(da2, cout, 0, 0, cout)],
+                         dx_rows=M, dx_hw=hw)]
+            biases = [self._pgrad(mod.out_layers[3].bias)]
+            if need_raw:
+                dxs, coff = [], 0
+                for s in srcs:
+                    g, acc = self._gacc(P, s)
+                    dxs.append((g, s.c, acc, coff, s.c))
+                    coff += s.c
+                segs.append(dict(planes=raw, c=cin, ntaps=1, hw_src=hw, wb="B:" + name + ".skip.w",
+                                 wgrad=self._pgrad(mod.skip_connection.weight).view(cout, cin), dx=dxs, dx_rows=M, dx_hw=hw))
+                biases.append(self._pgrad(mod.skip_connection.bias))
+            else:
+                g, acc = self._gacc(P, srcs[0])
+                if acc:
+                    bops.append((self.lib.wd_add, (g.data_ptr(), dO.data_ptr(), g.numel()), name + ":dresid"))
+                else:
+                    bops.append((self.lib.wd_copy2d, (g.data_ptr(), 4 * cout, dO.data_ptr(), 4 * cout, 4 * cout, M),
+                                 name + ":dresid"))
+            self._bwd_linear(P, name + ".conv2", dO, M, cout, hw, segs, bias=biases)
+            self._gn_bwd(P, name + ".gn2", [h1], mod.out_layers[0], 1e-5, True, da2)
+            da1 = self._f32(P, M, cin)
+            self._bwd_linear(P, name + ".conv1", h1.g, M, cout, hw,
+                             [dict(planes=a1, c=cin, ntaps=9, ftab=tab, btab=btab, hw_src=hw, wb="B:" + name + ".c1.w",
+                                   wgrad=self._pgrad(mod.in_layers[2].weight).view(cout, -1), dx=[(da1, cin, 0, 0, cin)],
+                                   dx_rows=M, dx_hw=hw)],
+                             bias=[self._pgrad(mod.in_layers[2].bias)], film_off=self.film_off[name])
+            self._gn_bwd(P, name + ".gn1", srcs, mod.in_layers[0], 1e-5, True, da1)
+            if parts is not None:
+                coff = 0
+                for s in parts:
+                    g, acc = self._gacc(P, s)
+                    dst = self._f32(P, M, s.c) if acc else g
+                    bops.append((self.lib.wd_copy2d, (dst.data_ptr(), 4 * s.c, srcs[0].g.data_ptr() + 4 * coff, 4 * cin, 4 * s.c,
+                                                      M), name + ":d(concat)"))
+                    if acc:
+                        bops.append((self.lib.wd_add, (g.data_ptr(), dst.data_ptr(), g.numel()), name + ":d(concat)+"))
+                    coff += s.c
+
+        self._tape.append(bwd)
+        return out
+
+    def _resample(self, P, name, mod, x: TAct, mode: str) -> TAct:
+        ops = P.step
+        B = self._B
+        tab, ho, wo = self._table(x.h, x.w, mode)
+        hw_in, M_in = x.h * x.w, B * x.h * x.w
+        pl = self._planes(P, M_in, x.c)
+        ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, M_in, x.c, 0, pl[0].data_ptr(),
+                                        pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
+        outt = self._f32(P, B * ho * wo, mod.cout)
+        gg = self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, hw_in)], name + ".w", B * ho * wo, ho * wo,
+                        bias=self._w[name + ".b"], out_f32=outt, out_ld=mod.cout, want_stats=True)
+        out = TAct(outt, mod.cout, ho, wo, gg._stats)
+        conv = mod.op if mode == "down" else mod.conv
+
+        def bwd():
+            bops = P.bwd
+            assert out.gw, name
+            M_out, hw_out = B * ho * wo, ho * wo
+            g, acc = self._gacc(P, x)
+            if mode == "down":
+                btab = self._btable(x.h, x.w, "down")
+                dx, dx_rows, dx_hw = [(g, x.c, acc, 0, x.c)], M_in, hw_in
+            else:  # nearest x2: data gradient at the upsampled resolution, then 2x2 sums
+                btab = self._btable(ho, wo, "same")
+                du = self._f32(P, M_out, x.c)
+                dx, dx_rows, dx_hw = [(du, x.c, 0, 0, x.c)], M_out, hw_out
+            self._bwd_linear(P, name + ".conv", out.g, M_out, mod.cout, hw_out,
+                             [dict(planes=pl, c=x.c, ntaps=9, ftab=tab, btab=btab, hw_src=hw_in, wb="B:" + name + ".w",
+                                   wgrad=self._pgrad(conv.weight).view(mod.cout, -1), dx=dx, dx_rows=dx_rows, dx_hw=dx_hw)],
+                             bias=[self._pgrad(conv.bias)])
+            if mode == "up":
+                if acc:
+                    tmp = self._f32(P, M_in, x.c)
+                    bops.append((self.lib.wd_pool2x2_sum, (du.data_ptr(), B, x.h, x.w, x.c, tmp.data_ptr()), name + ":pool"))
+                    bops.append((self.lib.wd_add, (g.data_ptr(), tmp.data_ptr(), g.numel()), name + ":pool+"))
+                else:
+                    bops.append((self.lib.wd_pool2x2_sum, (du.data_ptr(), B, x.h, x.w, x.c, g.data_ptr()), name + ":pool"))
+
+        self._tape.append(bwd)
+        return out
+
+    def _transformer(self, P, name, mod: SpatialTransformerParams, x: TAct) -> TAct:
+        ops = P.step
+        lib = self.lib
+        B = self._B
+        h, w, c = x.h, x.w, x.c
+        hw, M = h * w, B * h * w
+        heads, d = mod.heads, mod.d_head
+        inner = heads * d
+        L = self._ctx_len
+        scale = d ** -0.5
+        lo_ok = self.npass == 3
+        gpl, _ = self._gn(P, ops, name + ".gn", [x], name + ".gn", 1e-6, False)
+        self._gn_names[id(mod.norm)] = name + ".gn"
+        tok = self._f32(P, M, inner)
+        self._gemm(ops, name + ".proj_in", [self._src(gpl, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
+                   out_f32=tok, out_ld=inner)
+        saved = []
+        cur = tok
+        for di, tb in enumerate(mod.transformer_blocks):
+            p = f"{name}.tb{di}"
+            rec = dict(tb=tb, p=p, tok=cur)
+            # both attentions read norm2 in the base model (unet.py:337-345)
+            for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
+                n_pl = self._ln(P, ops, f"{p}.norm2({tag})", cur, M, inner, p + ".norm2")
+                q = self._f32(P, M, inner)
+                self._gemm(ops, f"{p}.{tag}.q", [self._src(n_pl, inner)], f"{p}.{tag}.q.w", M, hw, out_f32=q, out_ld=inner)
+                ko = self.kv_off[f"{p}.{tag}"]
+                o = self._planes(P, M, inner)
+                self._attention(ops, f"{p}.{tag}", q.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                                self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o)
+                nxt = self._f32(P, M, inner)
+                self._gemm(ops, f"{p}.{tag}.out", [self._src(o, inner)], f"{p}.{tag}.o.w", M, hw,
+                           bias=self._w[f"{p}.{tag}.o.b"], resid=cur.data_ptr(), resid_ld=inner, out_f32=nxt, out_ld=inner)
+                rec[tag] = dict(at=at, x=cur, n=n_pl, q=q, o=o, ko=ko)
+                cur = nxt
+            ffi = tb.ff.net[2].in_features
+            n3 = self._ln(P, ops, p + ".norm3", cur, M, inner, p + ".norm3")
+            u = self._f32(P, M, 2 * ffi)
+            self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1u.w", M, hw, bias=self._w[p + ".ff1u.b"], out_f32=u,
+                       out_ld=2 * ffi)
+            ffh = self._planes(P, M, ffi)
+            ops.append((lib.wd_geglu_fwd, (u.data_ptr(), 2 * ffi, M, ffi, ffh[0].data_ptr(), ffh[1].data_ptr() if lo_ok else None,
+                                           ffi), p + ".geglu"))
+            nxt = self._f32(P, M, inner)
+            xpl = self._planes(P, M, inner)
+            self._gemm(ops, p + ".ff2", [self._src(ffh, ffi)], p + ".ff2.w", M, hw, bias=self._w[p + ".ff2.b"],
+                       resid=cur.data_ptr(), resid_ld=inner, out_f32=nxt, out_ld=inner, out_pl=xpl)
+            rec.update(x3=cur, n3=n3, u=u, ffh=ffh, ffi=ffi, out=nxt, xpl=xpl)
+            saved.append(rec)
+            cur = nxt
+        outt = self._f32(P, M, c)
+        gg = self._gemm(ops, name + ".proj_out", [self._src(saved[-1]["xpl"], inner)], name + ".po.w", M, hw,
+                        bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=outt, out_ld=c,
+                        want_stats=True)
+        out = TAct(outt, c, h, w, gg._stats)
+
+        def bwd():
+            bops = P.bwd
+            assert out.gw, name
+            dO = out.g
+            g, acc = self._gacc(P, x)
+            if acc:
+                bops.append((lib.wd_add, (g.data_ptr(), dO.data_ptr(), g.numel()), name + ":dresid"))
+            else:
+                bops.append((lib.wd_copy2d, (g.data_ptr(), 4 * c, dO.data_ptr(), 4 * c, 4 * c, M), name + ":dresid"))
+            dcur = self._f32(P, M, inner)  # gradient of the running token stream (residual adds share it)
+            self._bwd_linear(P, name + ".proj_out", dO, M, c, hw,
+                             [dict(planes=saved[-1]["xpl"], c=inner, ntaps=1, hw_src=hw, wb="B:" + name + ".po.w",
+                                   wgrad=self._pgrad(mod.proj_out.weight).view(c, inner), dx=[(dcur, inner, 0, 0, inner)],
+                                   dx_rows=M, dx_hw=hw)], bias=[self._pgrad(mod.proj_out.bias)])
+            for rec in reversed(saved):
+                tb, p, ffi = rec["tb"], rec["p"], rec["ffi"]
+                # ---- feed-forward: out = ff2(geglu(ff1(LN3(x3)))) + x3
+                dffh = self._f32(P, M, ffi)
+                self._bwd_linear(P, p + ".ff2", dcur, M, inner, hw,
+                                 [dict(planes=rec["ffh"], c=ffi, ntaps=1, hw_src=hw, wb="B:" + p + ".ff2.w",
+                                       wgrad=self._pgrad(tb.ff.net[2].weight), dx=[(dffh, ffi, 0, 0, ffi)], dx_rows=M,
+                                       dx_hw=hw)], bias=[self._pgrad(tb.ff.net[2].bias)])
+                du = self._f32(P, M, 2 * ffi)
+                bops.append((lib.wd_geglu_bwd, (rec["u"].data_ptr(), 2 * ffi, dffh.data_ptr(), ffi, M, ffi, du.data_ptr(), 2 * ffi),
+                             p + ".geglu:bwd"))
+                dn3 = self._f32(P, M, inner)
+                self._bwd_linear(P, p + ".ff1", du, M, 2 * ffi, hw,
+                                 [dict(planes=rec["n3"], c=inner, ntaps=1, hw_src=hw, wb="B:" + p + ".ff1.w",
+                                       wgrad=self._pgrad(tb.ff.net[0].proj.weight), dx=[(dn3, inner, 0, 0, inner)], dx_rows=M,
+                                       dx_hw=hw)], bias=[self._pgrad(tb.ff.net[0].proj.bias)])
+                self._ln_bwd(P, p + ".norm3:bwd", rec["x3"], M, inner, tb.norm3, p + ".norm3", dn3, dcur, 1)
+                # ---- the two cross-attentions, last first
+                for tag in ("a2", "a1"):
+                    r = rec[tag]
+                    at = r["at"]
+                    do = self._f32(P, M, inner)
+                    self._bwd_linear(P, f"{p}.{tag}.out", dcur, M, inner, hw,
+                                     [dict(planes=r["o"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.{tag}.o.w",
+                                           wgrad=self._pgrad(at.to_out[0].weight), dx=[(do, inner, 0, 0, inner)], dx_rows=M,
+                                           dx_hw=hw)], bias=[self._pgrad(at.to_out[0].bias)])
+                    dq = self._f32(P, M, inner)
+                    ko = r["ko"]
+                    self._attn_bwd(P, f"{p}.{tag}:bwd", r["q"].data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                                   self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, do, heads, hw, L, d, scale,
+                                   dq.data_ptr(), inner, self._dkv.data_ptr() + 4 * ko, self.kv_total)
+                    dn = self._f32(P, M, inner)
+                    self._bwd_linear(P, f"{p}.{tag}.q", dq, M, inner, hw,
+                                     [dict(planes=r["n"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.{tag}.q.w",
+                                           wgrad=self._pgrad(at.to_q.weight), dx=[(dn, inner, 0, 0, inner)], dx_rows=M,
+                                           dx_hw=hw)])
+                    self._ln_bwd(P, f"{p}.norm2({tag}):bwd", r["x"], M, inner, tb.norm2, p + ".norm2", dn, dcur, 1)
+            dg = self._f32(P, M, c)
+            self._bwd_linear(P, name + ".proj_in", dcur, M, inner, hw,
+                             [dict(planes=gpl, c=c, ntaps=1, hw_src=hw, wb="B:" + name + ".pi.w",
+                                   wgrad=self._pgrad(mod.proj_in.weight).view(inner, c), dx=[(dg, c, 0, 0, c)], dx_rows=M,
+                                   dx_hw=hw)], bias=[self._pgrad(mod.proj_in.bias)])
+            self._gn_bwd(P, name + ".gn", [x], mod.norm, 1e-6, False, dg)
+
+        self._tape.append(bwd)
+        return out
+
+    # ------------------------------------------------------------------------------------------ plan
+    def _size_scratch(self, B, H, W, L):
+        m = self.model
+        mc = m.model_channels
+        cmax = mc * max(m.channel_mult)
+        M = B * H * W
+        mpad = _rup(M, 64)
+        nmax = max(8 * cmax, self.film_total, self.kv_total, 4 * mc)        # widest d(output): GEGLU pre-activation
+        kmax = max(9 * 2 * cmax, 4 * cmax, 4 * mc, self.kpad_in)           # longest (tap, channel) list: 3x3 over a concat
+        self._max_dpl = M * nmax
+        self._max_doutT = nmax * mpad
+        self._max_xT = kmax * mpad
+        self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)
+        self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)
+        self._scratch("xT", 2 * self._max_xT, torch.bfloat16)
+        self._cs_scratch = self._scratch("colsum", max(1 << 22, (M // 64 + 1) * nmax), torch.float32)
+        if self._ws is None or self._ws.numel() < 8 * 2 * cmax * 9 * cmax:
+            self._ws = torch.empty(max(128 * 128 * 160 * 8, 8 * 2 * cmax * 9 * cmax), dtype=torch.float32, device=self.device)
+
+    def plan_train(self, B: int, H: int, W: int, ctx_len: int) -> TrainPlan:
+        key = (B, H, W, ctx_len, self.npass)
+        if key in self._tplans:
+            return self._tplans[key]
+        if self._tplans:
+            # scratch buffers and the gradient-accumulate flags are sized / decided per plan: one live shape at a time
+            self._tplans.clear()
+            self._scr = {k: v for k, v in self._scr.items() if isinstance(k, tuple)}
+        m = self.model
+        lib = self.lib
+        if ctx_len == 0:
+            raise NotImplementedError("context=None: every reference script conditions on the word (unet.py:1605)")
+        P = TrainPlan()
+        self._cur_plan = P
+        self._B = B
+        L = ctx_len
+        self._ctx_len = L
+        self._tape = []
+        self._pw = set()
+        self._gn_names = {}
+        dev = self.device
+        mc = m.model_channels
+        ted = 4 * mc
+        cd = m.context_dim
+        lo_ok = self.npass == 3
+        self._size_scratch(B, H, W, L)
+        step = P.step
+
+        P.x_in = torch.zeros((B, m.in_channels, H, W), dtype=torch.float32, device=dev)
+        P.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        P.y_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        P.ctx_in = torch.zeros((B, L), dtype=torch.int64, device=dev)
+
+        # ---- conditioning path (differentiated, so it is part of every step): CharacterEncoder + all K/V projections
+        we = m.word_emb
+        if L > m.max_seq_len:
+            raise ValueError(f"context length {L} exceeds max_seq_len {m.max_seq_len} (the reference fails too)")
+        e = self._planes(P, B * L, cd)
+        step.append((lib.wd_embed_tokens, (P.ctx_in.data_ptr(), 1, B * L, L, self._w["we.table"].data_ptr(),
+                                           self._w["we.table"].shape[0], cd, self._w["pe"].data_ptr(), e[0].data_ptr(),
+                                           e[1].data_ptr() if lo_ok else None, cd), "word_emb.embedding"))
+        qkv = self._f32(P, B * L, 3 * cd)
+        self._gemm(step, "word_emb.qkv", [self._src(e, cd)], "we.qkv.w", B * L, L, bias=self._w["we.qkv.b"], out_f32=qkv,
+                   out_ld=3 * cd)
+        ctx_pl = self._planes(P, B * L, cd)
+        self._attention(step, "word_emb.attention", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
+                        qkv.data_ptr() + 8 * cd, 3 * cd, 1, L, L, cd, 1.0, ctx_pl, out_rows=L, out_row0=0)
+        self._kv = self._f32(P, B * L, self.kv_total)
+        self._dkv = self._f32(P, B * L, self.kv_total)
+        self._gemm(step, "cross.kv", [self._src(ctx_pl, cd)], "kv.w", B * L, L, out_f32=self._kv, out_ld=self.kv_total)
+
+        # ---- time / writer embedding with the SiLU pre-activations kept
+        te = self._planes(P, B, mc)
+        step.append((lib.wd_timestep_embedding, (P.t_in.data_ptr(), B, self._w["freqs"].data_ptr(), mc // 2, te[0].data_ptr(),
+                                                 te[1].data_ptr() if lo_ok else None, mc), "timestep_embedding"))
+        pre1 = self._f32(P, B, ted)
+        self._gemm(step, "time_embed.0", [self._src(te, mc)], "te0.w", B, 1, bias=self._w["te0.b"], out_f32=pre1, out_ld=ted)
+        e1 = self._planes(P, B, ted)
+        step.append((lib.wd_split, (pre1.data_ptr(), ted, B, ted, 1, e1[0].data_ptr(), e1[1].data_ptr() if lo_ok else None, ted),
+                     "time_embed.1(SiLU)"))
+        has_lab = m.num_classes is not None
+        pre2 = self._f32(P, B, ted)
+        self._gemm(step, "time_embed.2+label", [self._src(e1, ted)], "te2.w", B, 1, bias=self._w["te2.b"],
+                   resid=self._w["label"].data_ptr() if has_lab else None, resid_ld=ted if has_lab else 0,
+                   resid_rows=P.y_in.data_ptr() if has_lab else None, out_f32=pre2, out_ld=ted)
+        e2 = self._planes(P, B, ted)
+        step.append((lib.wd_split, (pre2.data_ptr(), ted, B, ted, 1, e2[0].data_ptr(), e2[1].data_ptr() if lo_ok else None, ted),
+                     "emb_layers.0(SiLU)"))
+        self._film = self._f32(P, B, self.film_total)
+        self._dfilm = self._f32(P, B, self.film_total)
+        self._gemm(step, "emb_layers(all)", [self._src(e2, ted)], "film.w", B, 1, bias=self._w["film.b"], out_f32=self._film,
+                   out_ld=self.film_total)
+
+        # ---- trunk
+        xin = self._planes(P, B * H * W, self.kpad_in)
+        step.append((lib.wd_im2col3x3, (P.x_in.data_ptr(), B, m.in_channels, H, W, xin[0].data_ptr(),
+                                        xin[1].data_ptr() if lo_ok else None, self.kpad_in), "im2col"))
+        h0 = self._f32(P, B * H * W, mc)
+        g0 = self._gemm(step, "input_blocks.0", [self._src(xin, self.kpad_in)], "in.w", B * H * W, H * W, bias=self._w["in.b"],
+                        out_f32=h0, out_ld=mc, want_stats=True)
+        first = TAct(h0, mc, H, W, g0._stats)
+        cur = first
+        hs = [cur]
+
+        def run_layers(prefix, blk, cur, extra=None):
+            for j, mod in enumerate(blk):
+                name = f"{prefix}.{j}"
+                if isinstance(mod, ResBlockParams):
+                    cur = self._resblock(P, name, mod, [cur] + ([extra] if (extra is not None and j == 0) else []))
+                elif isinstance(mod, SpatialTransformerParams):
+                    cur = self._transformer(P, name, mod, cur)
+                elif isinstance(mod, DownsampleParams):
+                    cur = self._resample(P, name, mod, cur, "down")
+                elif isinstance(mod, UpsampleParams):
+                    cur = self._resample(P, name, mod, cur, "up")
+                else:
+                    raise TypeError(type(mod))
+            return cur
+
+        for i, blk in enumerate(m.input_blocks):
+            if i == 0:
+                continue
+            cur = run_layers(f"in{i}", blk, cur)
+            hs.append(cur)
+        cur = run_layers("mid", m.middle_block, cur)
+        for i, blk in enumerate(m.output_blocks):
+            cur = run_layers(f"out{i}", blk, cur, extra=hs.pop())
+        last = cur
+        self._gn_names[id(m.out[0])] = "out.gn"
+        gpl, _ = self._gn(P, step, "out.gn", [last], "out.gn", 1e-5, True)
+        tab, _, _ = self._table(last.h, last.w, "same")
+        oc = m.out_channels
+        Mo, hwo = B * last.h * last.w, last.h * last.w
+        otok = self._f32(P, Mo, oc)
+        self._gemm(step, "out.conv", [self._src(gpl, last.c, 9, tab, hwo)], "out.w", Mo, hwo, bias=self._w["out.b"],
+                   out_f32=otok, out_ld=oc)
+        P.out = torch.empty((B, oc, last.h, last.w), dtype=torch.float32, device=dev)
+        step.append((lib.wd_tokens_to_nchw, (otok.data_ptr(), oc, B, oc, hwo, P.out.data_ptr()), "tokens_to_nchw"))
+
+        # ================================ backward list ================================
+        bops = P.bwd
+        P.dout = torch.zeros((B, oc, last.h, last.w), dtype=torch.float32, device=dev)
+        if oc > 32:
+            raise NotImplementedError("out_channels > 32")
+        dtok = torch.zeros((Mo, 32), dtype=torch.float32, device=dev)  # columns >= oc stay zero
+        P.keep.append(dtok)
+        bops.append((lib.wd_nchw_to_tokens, (P.dout.data_ptr(), B, oc, hwo, dtok.data_ptr(), 32), "d(out):tokens"))
+        dg = self._f32(P, Mo, last.c)
+        self._bwd_linear(P, "out.conv", dtok, Mo, oc, hwo,
+                         [dict(planes=gpl, c=last.c, ntaps=9, ftab=tab, btab=self._btable(last.h, last.w, "same"), hw_src=hwo,
+                               wb="B:out.w", wgrad=self._pgrad(m.out[2].weight).view(oc, -1), dx=[(dg, last.c, 0, 0, last.c)],
+                               dx_rows=Mo, dx_hw=hwo)], bias=[self._pgrad(m.out[2].bias)], npad=32)
+        self._gn_bwd(P, "out.gn", [last], m.out[0], 1e-5, True, dg)
+        for fn in reversed(self._tape):
+            fn()
+        # ---- input convolution: weight / bias gradient only
+        assert first.gw
+        cin0 = m.in_channels
+        packed = self._f32(P, mc, self.kpad_in)
+        self._bwd_linear(P, "input_blocks.0", first.g, B * H * W, mc, H * W,
+                         [dict(planes=xin, c=self.kpad_in, ntaps=1, hw_src=H * W,
+                               wgrad_packed=(packed, self._pgrad(m.input_blocks[0][0].weight), cin0))],
+                         bias=[self._pgrad(m.input_blocks[0][0].bias)])
+        # ---- FiLM projections -> time embedding MLP / writer embedding
+        film_w = self._pgroup([l.weight for l in self._film_mods])
+        film_b = self._pgroup([l.bias for l in self._film_mods])
+        de2 = self._f32(P, B, ted)
+        self._bwd_linear(P, "emb_layers(all)", self._dfilm, B, self.film_total, 1,
+                         [dict(planes=e2, c=ted, ntaps=1, hw_src=1, wb="B:film.w", wgrad=film_w, dx=[(de2, ted, 0, 0, ted)],
+                               dx_rows=B, dx_hw=1)], bias=[film_b])
+        dpre2 = self._f32(P, B, ted)
+        bops.append((lib.wd_silu_bwd, (pre2.data_ptr(), de2.data_ptr(), B * ted, dpre2.data_ptr()), "emb SiLU:bwd"))
+        if has_lab:
+            dl = self._pgrad(m.label_emb.weight)
+            bops.append((lib.wd_embedding_bwd, (P.y_in.data_ptr(), 1, B, dpre2.data_ptr(), ted, m.num_classes, ted, dl.data_ptr(),
+                                                self._pacc(dl)), "label_emb:bwd"))
+        de1 = self._f32(P, B, ted)
+        self._bwd_linear(P, "time_embed.2", dpre2, B, ted, 1,
+                         [dict(planes=e1, c=ted, ntaps=1, hw_src=1, wb="B:te2.w", wgrad=self._pgrad(m.time_embed[2].weight),
+                               dx=[(de1, ted, 0, 0, ted)], dx_rows=B, dx_hw=1)], bias=[self._pgrad(m.time_embed[2].bias)])
+        dpre1 = self._f32(P, B, ted)
+        bops.append((lib.wd_silu_bwd, (pre1.data_ptr(), de1.data_ptr(), B * ted, dpre1.data_ptr()), "time SiLU:bwd"))
+        self._bwd_linear(P, "time_embed.0", dpre1, B, ted, 1,
+                         [dict(planes=te, c=mc, ntaps=1, hw_src=1, wgrad=self._pgrad(m.time_embed[0].weight))],
+                         bias=[self._pgrad(m.time_embed[0].bias)])
+        # ---- K/V projections -> word encoder
+        kv_params = []
+        for at in self._kv_mods:
+            kv_params += [at.to_k.weight, at.to_v.weight]
+        kv_w = self._pgroup(kv_params)
+        dctx = self._f32(P, B * L, cd)
+        self._bwd_linear(P, "cross.kv", self._dkv, B * L, self.kv_total, L,
+                         [dict(planes=ctx_pl, c=cd, ntaps=1, hw_src=L, wb="B:kv.w", wgrad=kv_w, dx=[(dctx, cd, 0, 0, cd)],
+                               dx_rows=B * L, dx_hw=L)])
+        dqkv = self._f32(P, B * L, 3 * cd)
+        self._attn_bwd(P, "word_emb.attention:bwd", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
+                       qkv.data_ptr() + 8 * cd, 3 * cd, dctx, 1, L, L, cd, 1.0, dqkv.data_ptr(), 3 * cd,
+                       dqkv.data_ptr() + 4 * cd, 3 * cd)
+        at = we.attention
+        qkv_w = self._pgroup([at.linear_query.weight, at.linear_key.weight, at.linear_value.weight])
+        qkv_b = self._pgroup([at.linear_query.bias, at.linear_key.bias, at.linear_value.bias])
+        de = self._f32(P, B * L, cd)
+        self._bwd_linear(P, "word_emb.qkv", dqkv, B * L, 3 * cd, L,
+                         [dict(planes=e, c=cd, ntaps=1, hw_src=L, wb="B:we.qkv.w", wgrad=qkv_w, dx=[(de, cd, 0, 0, cd)],
+                               dx_rows=B * L, dx_hw=L)], bias=[qkv_b])
+        dtab = self._pgrad(we.embedding.weight)
+        bops.append((lib.wd_embedding_bwd, (P.ctx_in.data_ptr(), 1, B * L, de.data_ptr(), cd, we.embedding.weight.shape[0], cd,
+                                            dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
+        self._tape = []
+        self._tplans[key] = P
+        return P
+
+    # ------------------------------------------------------------------------------------------ run
+    def forward_train(self, x, t, context, y):
+        """Training forward: keeps every intermediate for ``backward``.  Returns the plan's output buffer (no copy)."""
+        self.refresh_weights()
+        B, _, H, W = x.shape
+        if context is None:
+            raise NotImplementedError("context=None")
+        P = self.plan_train(B, H, W, context.shape[1])
+        P.x_in.copy_(x, non_blocking=True)
+        P.t_in.copy_(t, non_blocking=True)
+        P.ctx_in.copy_(context, non_blocking=True)
+        if y is not None:
+            P.y_in.copy_(y, non_blocking=True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        P.run_step(stream)
+        self._live = P
+        return P.out
+
+    def backward(self, dout: torch.Tensor, assign: bool = True):
+        """Runs the backward list for d loss / d out (NCHW) and points ``param.grad`` at the gradient buffers (adding to
+        a ``.grad`` the caller kept, like autograd's accumulation)."""
+        P = self._live
+        kept = []
+        if assign:
+            for k, p in self._params.items():
+                if p.grad is not None:
+                    # the caller did not reset this gradient to None (zero_grad(set_to_none=False) / accumulation)
+                    kept.append((k, p.grad.clone() if p.grad.data_ptr() == self._grad[k].data_ptr() else p.grad))
+        P.dout.copy_(dout, non_blocking=True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        P.run_bwd(stream)
+        if assign:
+            for k, old in kept:
+                self._grad[k].add_(old)
+            self.assign_grads()
+
+    def assign_grads(self):
+        for k, p in self._params.items():
+            p.grad = self._grad[k]
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        return {names[k]: g for k, g in self._grad.items()}
