@@ -187,6 +187,19 @@ int wd_adamw_chunk(void);
 int wd_adamw_multi(const void* table, int ntensor, int64_t total_chunks, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, int ema_mode, double ema_beta, void* stream);
 
+/* Table-driven weight repack (one launch refreshes every packed operand after an optimiser step; the reference reads
+ * its parameters in place, unet.py forward).  Entry layout (wd_repack_entry_bytes() = 72 bytes, little endian):
+ *   u64 src0, u64 src1 (0 = none), u64 dst_hi, u64 dst_lo, i32 N, C, T, mode, i32 npad, ld, g, ntile_c, i64 chunk0
+ * mode 0: dst[perm_g(n)][t*C + c]   = split(src0[n][c][t])   (forward operand; perm_g = GEGLU x|gate interleave, g=0 none)
+ * mode 1: dst[c][t*npad + n]        = split(src0[n][c][t]), 0 for N <= n < npad   (data-gradient operand)
+ * mode 2: dstf[perm_g(i)]           = src0[i] (+ src1[i]), i < N   (fp32 vectors)
+ * dst pointers are pre-offset to the piece's (row, column) origin; ld = row pitch in elements.  A mode-0/1 piece owns
+ * ceil(N or npad / tile) * ceil(C / tile) chunks (tile = wd_repack_tile()), a mode-2 piece ceil(N / wd_repack_vchunk()). */
+int wd_repack_entry_bytes(void);
+int wd_repack_tile(void);
+int wd_repack_vchunk(void);
+int wd_repack_multi(const void* table, int nentries, int64_t total_chunks, void* stream);
+
 /* loss = mean((pred - target)^2) (nn.MSELoss, train.py:289; deterministic two-stage sum) and, when grad != NULL,
  * grad = d loss / d pred = 2 (pred - target) / n.  scratch: >= min(1024, ceil(n/256)) doubles. */
 int wd_mse_loss(const float* pred, const float* target, int64_t n, float* grad, float* loss, double* scratch,

@@ -310,3 +310,33 @@ def test_training_step_gradients_match_oracle_autograd(cfg_name, B, hw):
     torch.cuda.synchronize()
     k0 = "input_blocks.1.0.in_layers.2.weight"
     assert max_rel(params[k0].grad, 2 * g1[k0]) < 1e-6
+
+
+@pytest.mark.parametrize("variant,train", [("base", False), ("phosc", False), ("base", True)])
+def test_device_repack_equals_host_specification(variant, train):
+    """wd_repack_multi (one launch for every operand) against _Recipe.host(): the split-bf16 planes must be exactly
+    split(host matrix) and the fp32 vectors bit-identical; a parameter update is picked up by the next refresh."""
+    m = build(DEEP, variant, variant == "phosc", seed=5)
+    eng = m.train_engine if train else m.engine
+    eng.refresh_weights()
+    torch.cuda.synchronize()
+    book = eng._recipes()
+    assert len(book) > 50
+    for name, r in book.items():
+        want = r.host()
+        got = eng._w[name]
+        if r.planes:
+            hi = want.to(torch.bfloat16)
+            lo = (want - hi.float()).to(torch.bfloat16)
+            assert torch.equal(got[0], hi) and torch.equal(got[1], lo), name
+        else:
+            assert torch.equal(got, want), name
+    with torch.no_grad():
+        m.out[2].weight.mul_(1.5)
+        m.input_blocks[1][0].in_layers[2].bias.add_(0.25)
+    eng.refresh_weights()
+    torch.cuda.synchronize()
+    for name in ("out.w", "in1.0.c1.b"):
+        want = eng._recipes()[name].host()
+        got = eng._w[name]
+        assert torch.equal(got[0], want.to(torch.bfloat16)) if got.dtype == torch.bfloat16 else torch.equal(got, want), name

@@ -89,7 +89,7 @@ def test_engine_recipes_cover_the_forward(golden_dir):
     rec = eng._recipes()
     name = "out0.0"  # ResBlock(128 -> 64) with a 1x1 skip
     rb = m.output_blocks[0][0]
-    wcat = rec[name + ".c2.w"]()
+    wcat = rec[name + ".c2.w"].host()
     assert wcat.shape == (64, 9 * 64 + 128)
     x = torch.randn(2, 128, 4, 8)
     h = torch.randn(2, 64, 4, 8)
@@ -99,12 +99,28 @@ def test_engine_recipes_cover_the_forward(golden_dir):
     tok = torch.cat([h.permute(0, 2, 3, 1).reshape(2, 32, 64), torch.zeros(2, 1, 64)], 1)
     a = torch.cat([tok[:, torch.from_numpy(tab[t]).long()] for t in range(9)] +
                   [x.permute(0, 2, 3, 1).reshape(2, 32, 128)], dim=2)
-    out = (a @ wcat.t() + rec[name + ".c2.b"]()).reshape(2, 4, 8, 64).permute(0, 3, 1, 2)
+    out = (a @ wcat.t() + rec[name + ".c2.b"].host()).reshape(2, 4, 8, 64).permute(0, 3, 1, 2)
     assert torch.allclose(out, ref, atol=1e-4)
     # every ResBlock has a FiLM slice; K/V slices exist for both cross-attentions of every block (base variant)
     assert eng.film_total == sum(mod.cout for _, mod in eng._walk() if hasattr(mod, "emb_layers"))
     assert eng.kv_total == 2 * 64 * 2 * 4
-    assert rec["film.w"]().shape == (eng.film_total, 256)
+    assert rec["film.w"].host().shape == (eng.film_total, 256)
+    # GEGLU projection: x rows and gate rows interleaved per half tile; data-gradient operands are the transposes
+    tb = m.input_blocks[1][1].transformer_blocks[0]
+    from worddiffusion_amd.engine import geglu_interleave, geglu_tile
+    g_ = geglu_tile(tb.ff.net[2].in_features) % 1000 // 2
+    assert torch.equal(rec["in1.1.tb0.ff1.w"].host(), geglu_interleave(tb.ff.net[0].proj.weight.detach(), g_))
+    from worddiffusion_amd.backward import pack_dx_weight
+    from worddiffusion_amd.train_engine import TrainEngine
+    teng = TrainEngine.__new__(TrainEngine)
+    teng.model, teng.variant = m, "base"
+    trec = teng._recipes()
+    assert torch.equal(trec["B:out0.0.c1.w"].host(), pack_dx_weight(rb.in_layers[2].weight.detach()))
+    assert torch.equal(trec["B:out0.0.skip.w"].host(), pack_dx_weight(rb.skip_connection.weight.detach().flatten(1)))
+    pad = torch.zeros(32, 64, 3, 3)
+    pad[:4] = m.out[2].weight.detach()
+    assert torch.equal(trec["B:out.w"].host(), pack_dx_weight(pad))
+    assert torch.equal(trec["B:film.w"].host(), rec["film.w"].host().t())
 
 
 def test_c_abi_exports_every_declared_symbol():

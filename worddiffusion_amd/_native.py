@@ -64,6 +64,10 @@ _SIGS = {
                            C.c_double, _vp]),
     "wd_mse_loss": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _i, _vp]),
     "wd_transpose_planes": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wd_repack_entry_bytes": (_i, []),
+    "wd_repack_tile": (_i, []),
+    "wd_repack_vchunk": (_i, []),
+    "wd_repack_multi": (_i, [_vp, _i, C.c_int64, _vp]),
     "wd_add": (_i, [_vp, _vp, C.c_int64, _vp]),
     "wd_permute_dw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wd_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, C.c_int64, _vp]),

@@ -1,0 +1,106 @@
+// Weight repack on the device: reference-layout fp32 parameters (OIHW convolutions, [out, in] linears, vectors) -> the
+// operands the kernels consume (split-bf16 planes [rows][K], K = tap-major / channel-minor; the transposed
+// [C_in][tap][C_out] planes of the data-gradient GEMMs; concatenated / summed fp32 vectors).  One table-driven launch
+// refreshes every operand after an optimiser step (the reference re-reads its parameters in place each forward; here the
+// packed copies are part of the step), instead of ~10 small ATen launches per tensor.
+#include "wd_common.h"
+
+namespace {
+
+struct PackRef {        // one piece of one packed operand; built once by the host (engine.py)
+    const float* src0;  // [N][C][T] (T = 9 for 3x3 kernels, 1 for linears) or a vector of N floats
+    const float* src1;  // optional second addend (vectors only: conv bias + skip bias)
+    void* dst_hi;       // planes: bf16 hi plane, already offset to (row_off, col_off); vectors: fp32 destination
+    void* dst_lo;
+    int32_t N, C, T, mode;     // mode 0: forward planes, 1: data-gradient planes, 2: fp32 vector
+    int32_t npad, ld, g, ntile_c;
+    int64_t chunk0;     // index of this piece's first chunk (tile)
+};
+
+constexpr int PT = 32;          // tile: 32 output channels x 32 input channels x T taps
+constexpr int VCHUNK = 8192;    // vector elements per workgroup
+
+__device__ __forceinline__ int geglu_perm(int n, int N, int g) {
+    // rows [x | gate] -> blocks of g x-rows followed by their g gate rows (engine.geglu_interleave)
+    if (g <= 0) return n;
+    const int inner = N >> 1;
+    const int half = n >= inner;
+    const int m = half ? n - inner : n;
+    return (m / g) * 2 * g + half * g + (m % g);
+}
+
+__global__ void __launch_bounds__(256) repack_multi_kernel(const PackRef* __restrict__ tab, int nentries) {
+    __shared__ float s[PT * (PT * 9 + 1)];
+    int lo = 0, hi = nentries - 1;
+    const int64_t ch = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].chunk0 <= ch) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackRef e = tab[lo];
+    const int64_t lc = ch - e.chunk0;
+    const int tid = threadIdx.x;
+    if (e.mode == 2) {
+        float* dst = reinterpret_cast<float*>(e.dst_hi);
+        const int64_t base = lc * VCHUNK, end = base + VCHUNK < e.N ? base + VCHUNK : e.N;
+        for (int64_t i = base + tid; i < end; i += 256) {
+            float v = e.src0[i];
+            if (e.src1) v += e.src1[i];
+            dst[geglu_perm((int)i, e.N, e.g)] = v;
+        }
+        return;
+    }
+    const int T = e.T, C = e.C, N = e.N;
+    const int n0 = (int)(lc / e.ntile_c) * PT, c0 = (int)(lc % e.ntile_c) * PT;
+    const int nc = min(PT, C - c0);           // valid input channels in this tile
+    const int row = PT * T + 1;
+    // load: for each output channel the (c, t) block is contiguous in the OIHW source
+    for (int idx = tid; idx < PT * nc * T; idx += 256) {
+        const int nl = idx / (nc * T), rem = idx - nl * (nc * T);
+        const int n = n0 + nl;
+        s[nl * row + rem] = n < N ? e.src0[((int64_t)n * C + c0) * T + rem] : 0.f;
+    }
+    __syncthreads();
+    wd_bf16* dh = reinterpret_cast<wd_bf16*>(e.dst_hi);
+    wd_bf16* dl = reinterpret_cast<wd_bf16*>(e.dst_lo);
+    if (e.mode == 0) {
+        // dst[perm(n)][t * C + c]: c fastest
+        for (int idx = tid; idx < PT * T * nc; idx += 256) {
+            const int cl = idx % nc, t = (idx / nc) % T, nl = idx / (nc * T);
+            const int n = n0 + nl;
+            if (n >= N) continue;
+            uint32_t h, l;
+            wd_split1(s[nl * row + cl * T + t], h, l);
+            const int64_t o = (int64_t)geglu_perm(n, N, e.g) * e.ld + (int64_t)t * C + c0 + cl;
+            dh[o] = (wd_bf16)h;
+            if (dl) dl[o] = (wd_bf16)l;
+        }
+    } else {
+        // dst[c][t * npad + n]: n fastest (columns n >= N of the padded block are written as zeros)
+        const int nn = min(PT, e.npad - n0);
+        for (int idx = tid; idx < nc * T * nn; idx += 256) {
+            const int nl = idx % nn, t = (idx / nn) % T, cl = idx / (nn * T);
+            uint32_t h, l;
+            wd_split1(s[nl * row + cl * T + t], h, l);
+            const int64_t o = (int64_t)(c0 + cl) * e.ld + (int64_t)t * e.npad + n0 + nl;
+            dh[o] = (wd_bf16)h;
+            if (dl) dl[o] = (wd_bf16)l;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int wd_repack_entry_bytes(void) { return (int)sizeof(PackRef); }
+extern "C" int wd_repack_tile(void) { return PT; }
+extern "C" int wd_repack_vchunk(void) { return VCHUNK; }
+
+extern "C" int wd_repack_multi(const void* table, int nentries, int64_t total_chunks, void* stream) {
+    if (!table || nentries <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(repack_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, st,
+                       reinterpret_cast<const PackRef*>(table), nentries);
+    return wd_check_launch();
+}

@@ -109,6 +109,109 @@ def slab_span(tab: Optional[np.ndarray], hw_out: int, hw_src: int, m: int, bm: i
     return span
 
 
+class _Recipe:
+    __slots__ = ("name", "planes", "rows", "cols", "shape", "pieces")
+
+    def __init__(self, name, planes, rows=0, cols=0, shape=None):
+        self.name, self.planes, self.rows, self.cols, self.shape, self.pieces = name, planes, rows, cols, shape, []
+
+    @staticmethod
+    def _nct(w):
+        return w.shape[0], w.shape[1], (w.shape[2] * w.shape[3] if w.dim() == 4 else 1)
+
+    def fwd(self, w, row_off=0, col_off=0, g=0):
+        """[N, C(, kh, kw)] parameter -> rows row_off.., columns col_off + tap*C + c of this matrix."""
+        n, c, t = self._nct(w)
+        assert row_off + n <= self.rows and col_off + t * c <= self.cols, self.name
+        self.pieces.append((0, w, None, n, c, t, row_off, col_off, 0, g))
+        return self
+
+    def bwd(self, w, col_off=0, npad=None):
+        """[N, C(, kh, kw)] parameter -> rows c, columns col_off + tap*npad + n (the data-gradient operand)."""
+        n, c, t = self._nct(w)
+        npad = n if npad is None else npad
+        assert c <= self.rows and col_off + t * npad <= self.cols, self.name
+        self.pieces.append((1, w, None, n, c, t, 0, col_off, npad, 0))
+        return self
+
+    def vec(self, p, p2=None, off=0, g=0):
+        self.pieces.append((2, p, p2, p.numel(), 1, 1, 0, off, 0, g))
+        return self
+
+    def host(self) -> torch.Tensor:
+        """The packed operand in fp32, computed with torch on the parameters' device: the specification of
+        ``wd_repack_multi``'s index mapping (used by the tests; the product path never calls it)."""
+        first = self.pieces[0][1]
+        out = torch.zeros((self.rows, self.cols) if self.planes else (int(torch.tensor(self.shape).prod()),),
+                          dtype=torch.float32, device=first.device)
+        for (mode, p, p2, n, c, t, row_off, col_off, npad, g) in self.pieces:
+            src = p.detach().float()
+            if mode == 2:
+                v = src.reshape(-1) + (p2.detach().float().reshape(-1) if p2 is not None else 0)
+                out[col_off:col_off + n] = geglu_interleave(v, g) if g else v
+                continue
+            w3 = src.reshape(n, c, t)
+            if mode == 0:
+                blk = w3.permute(0, 2, 1).reshape(n, t * c)
+                out[row_off:row_off + n, col_off:col_off + t * c] = geglu_interleave(blk, g) if g else blk
+            else:
+                blk = torch.zeros(c, t, npad, dtype=torch.float32, device=first.device)
+                blk[:, :, :n] = w3.permute(1, 2, 0)
+                out[:c, col_off:col_off + t * npad] = blk.reshape(c, t * npad)
+        return out if self.planes else out.reshape(self.shape)
+
+
+class RecipeBook(dict):
+    """name -> _Recipe.  Matrices become split-bf16 planes [2, rows, cols]; vectors stay fp32."""
+
+    def matrix(self, name, rows, cols) -> _Recipe:
+        self[name] = _Recipe(name, True, rows, cols)
+        return self[name]
+
+    def vector(self, name, p, p2=None, g=0) -> _Recipe:
+        self[name] = _Recipe(name, False, shape=tuple(p.shape)).vec(p, p2, 0, g)
+        return self[name]
+
+    def vector_cat(self, name, ps) -> _Recipe:
+        r = _Recipe(name, False, shape=(sum(p.numel() for p in ps),))
+        off = 0
+        for p in ps:
+            r.vec(p, None, off)
+            off += p.numel()
+        self[name] = r
+        return r
+
+    def linear(self, name, lin):
+        self.matrix(name + ".w", lin.weight.shape[0], lin.weight.shape[1]).fwd(lin.weight)
+        if lin.bias is not None:
+            self.vector(name + ".b", lin.bias)
+
+    def device_table(self, lib, dst: Dict[str, torch.Tensor], dev):
+        """Serialises the pieces into the entry table of ``wd_repack_multi`` (include/wdiff_hip.h)."""
+        import struct
+        assert lib.wd_repack_entry_bytes() == 72
+        tile, vchunk = lib.wd_repack_tile(), lib.wd_repack_vchunk()
+        recs, c0 = [], 0
+        for name, r in self.items():
+            d = dst[name]
+            for (mode, p, p2, n, c, t, row_off, col_off, npad, g) in r.pieces:
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), name
+                if mode == 2:
+                    hi, lo, ld, ntc = d.data_ptr() + 4 * col_off, 0, 0, 1
+                    nch = (n + vchunk - 1) // vchunk
+                else:
+                    ld = r.cols
+                    o = 2 * (row_off * ld + col_off)
+                    hi, lo = d[0].data_ptr() + o, d[1].data_ptr() + o
+                    ntc = (c + tile - 1) // tile
+                    nch = (((npad if mode == 1 else n) + tile - 1) // tile) * ntc
+                recs.append(struct.pack("<QQQQiiiiiiiiq", p.data_ptr(), p2.data_ptr() if p2 is not None else 0, hi, lo, n, c, t,
+                                        mode, npad, ld, g, ntc, c0))
+                c0 += nch
+        raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        return raw, c0, len(recs)
+
+
 class Act:
     """A token-major fp32 feature map [B*h*w, c] on the device."""
     __slots__ = ("t", "c", "h", "w", "stats")
@@ -152,6 +255,7 @@ class UNetEngine:
         self.lib = N.lib()
         self.npass = 3
         self._sig = None
+        self._pack = None
         self._w: Dict[str, torch.Tensor] = {}
         self._w3: Dict[str, torch.Tensor] = {}      # slab-order copies of the matrices the v3 kernel consumes
         self._w3_meta: Dict[str, tuple] = {}
@@ -170,116 +274,111 @@ class UNetEngine:
             self.npass = npass
             self._plans.clear()
 
-    def _signature(self):
-        ps = list(self.model.parameters())
-        return (sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), str(ps[0].device))
-
-    def _recipes(self):
-        """name -> callable producing the fp32 matrix / vector the kernels consume (reference layouts in)."""
+    def _recipes(self) -> "RecipeBook":
+        """Declarative description of every operand the kernels consume: which parameter (reference layout) goes where in
+        which packed matrix / vector.  ``refresh_weights`` turns it into the device table of ``wd_repack_multi``."""
         m = self.model
-        rec = {}
-
-        def conv3(wt):  # [N, C, 3, 3] -> [N, 9*C] (tap-major, channel fastest)
-            return wt.permute(0, 2, 3, 1).reshape(wt.shape[0], -1)
-
-        def conv1(wt):
-            return wt.reshape(wt.shape[0], -1)
-
-        def padk(w2, kpad):
-            out = w2.new_zeros(w2.shape[0], kpad)
-            out[:, : w2.shape[1]] = w2
-            return out
-
-        film_w, film_b = [], []
+        R = RecipeBook()
+        film_w = []
         self.film_off = {}
         off = 0
         cin_conv = m.input_blocks[0][0]
         self.kpad_in = ((9 * cin_conv.in_channels + 31) // 32) * 32
-        rec["in.w"] = lambda: padk(conv3(cin_conv.weight), self.kpad_in)
-        rec["in.b"] = lambda: cin_conv.bias
-        rec["te0.w"] = lambda: m.time_embed[0].weight
-        rec["te0.b"] = lambda: m.time_embed[0].bias
-        rec["te2.w"] = lambda: m.time_embed[2].weight
-        rec["te2.b"] = lambda: m.time_embed[2].bias
+        R.matrix("in.w", cin_conv.out_channels, self.kpad_in).fwd(cin_conv.weight)
+        R.vector("in.b", cin_conv.bias)
+        R.linear("te0", m.time_embed[0])
+        R.linear("te2", m.time_embed[2])
         if m.num_classes is not None:
-            rec["label"] = lambda: m.label_emb.weight
+            R.vector("label", m.label_emb.weight)
         we = m.word_emb
-        rec["we.table"] = lambda: we.embedding.weight
-        rec["we.qkv.w"] = lambda: torch.cat([we.attention.linear_query.weight, we.attention.linear_key.weight,
-                                             we.attention.linear_value.weight], 0)
-        rec["we.qkv.b"] = lambda: torch.cat([we.attention.linear_query.bias, we.attention.linear_key.bias,
-                                             we.attention.linear_value.bias], 0)
+        cd = we.embedding.weight.shape[1]
+        R.vector("we.table", we.embedding.weight)
+        qkv = (we.attention.linear_query, we.attention.linear_key, we.attention.linear_value)
+        R.matrix("we.qkv.w", 3 * cd, cd)
+        R.vector_cat("we.qkv.b", [l.bias for l in qkv])
+        for i, l in enumerate(qkv):
+            R["we.qkv.w"].fwd(l.weight, row_off=i * cd)
         kv_w = []
         self.kv_off = {}
         kvo = 0
         for name, mod in self._walk():
             if isinstance(mod, ResBlockParams):
-                rec[name + ".gn1.g"] = (lambda mod=mod: mod.in_layers[0].weight)
-                rec[name + ".gn1.b"] = (lambda mod=mod: mod.in_layers[0].bias)
-                rec[name + ".c1.w"] = (lambda mod=mod: conv3(mod.in_layers[2].weight))
-                rec[name + ".c1.b"] = (lambda mod=mod: mod.in_layers[2].bias)
-                rec[name + ".gn2.g"] = (lambda mod=mod: mod.out_layers[0].weight)
-                rec[name + ".gn2.b"] = (lambda mod=mod: mod.out_layers[0].bias)
+                R.vector(name + ".gn1.g", mod.in_layers[0].weight)
+                R.vector(name + ".gn1.b", mod.in_layers[0].bias)
+                R.matrix(name + ".c1.w", mod.cout, 9 * mod.cin).fwd(mod.in_layers[2].weight)
+                R.vector(name + ".c1.b", mod.in_layers[2].bias)
+                R.vector(name + ".gn2.g", mod.out_layers[0].weight)
+                R.vector(name + ".gn2.b", mod.out_layers[0].bias)
                 if mod.cin != mod.cout:
-                    rec[name + ".c2.w"] = (lambda mod=mod: torch.cat(
-                        [conv3(mod.out_layers[3].weight), conv1(mod.skip_connection.weight)], 1))
-                    rec[name + ".c2.b"] = (lambda mod=mod: mod.out_layers[3].bias + mod.skip_connection.bias)
+                    # the 1x1 skip projection is a second K segment of the last 3x3 GEMM; the biases add
+                    R.matrix(name + ".c2.w", mod.cout, 9 * mod.cout + mod.cin).fwd(mod.out_layers[3].weight) \
+                        .fwd(mod.skip_connection.weight, col_off=9 * mod.cout)
+                    R.vector(name + ".c2.b", mod.out_layers[3].bias, mod.skip_connection.bias)
                 else:
-                    rec[name + ".c2.w"] = (lambda mod=mod: conv3(mod.out_layers[3].weight))
-                    rec[name + ".c2.b"] = (lambda mod=mod: mod.out_layers[3].bias)
+                    R.matrix(name + ".c2.w", mod.cout, 9 * mod.cout).fwd(mod.out_layers[3].weight)
+                    R.vector(name + ".c2.b", mod.out_layers[3].bias)
                 film_w.append(mod.emb_layers[1])
                 self.film_off[name] = off
                 off += mod.cout
-            elif isinstance(mod, DownsampleParams):
-                rec[name + ".w"] = (lambda mod=mod: conv3(mod.op.weight))
-                rec[name + ".b"] = (lambda mod=mod: mod.op.bias)
-            elif isinstance(mod, UpsampleParams):
-                rec[name + ".w"] = (lambda mod=mod: conv3(mod.conv.weight))
-                rec[name + ".b"] = (lambda mod=mod: mod.conv.bias)
+            elif isinstance(mod, (DownsampleParams, UpsampleParams)):
+                conv = mod.op if isinstance(mod, DownsampleParams) else mod.conv
+                R.matrix(name + ".w", mod.cout, 9 * mod.cin).fwd(conv.weight)
+                R.vector(name + ".b", conv.bias)
             elif isinstance(mod, SpatialTransformerParams):
-                rec[name + ".gn.g"] = (lambda mod=mod: mod.norm.weight)
-                rec[name + ".gn.b"] = (lambda mod=mod: mod.norm.bias)
-                rec[name + ".pi.w"] = (lambda mod=mod: conv1(mod.proj_in.weight))
-                rec[name + ".pi.b"] = (lambda mod=mod: mod.proj_in.bias)
-                rec[name + ".po.w"] = (lambda mod=mod: conv1(mod.proj_out.weight))
-                rec[name + ".po.b"] = (lambda mod=mod: mod.proj_out.bias)
+                inner = mod.heads * mod.d_head
+                R.vector(name + ".gn.g", mod.norm.weight)
+                R.vector(name + ".gn.b", mod.norm.bias)
+                R.matrix(name + ".pi.w", inner, mod.ch).fwd(mod.proj_in.weight)
+                R.vector(name + ".pi.b", mod.proj_in.bias)
+                R.matrix(name + ".po.w", mod.ch, inner).fwd(mod.proj_out.weight)
+                R.vector(name + ".po.b", mod.proj_out.bias)
                 for d, tb in enumerate(mod.transformer_blocks):
                     p = f"{name}.tb{d}"
                     for ln in ("norm1", "norm2", "norm3"):
-                        rec[f"{p}.{ln}.g"] = (lambda tb=tb, ln=ln: getattr(tb, ln).weight)
-                        rec[f"{p}.{ln}.b"] = (lambda tb=tb, ln=ln: getattr(tb, ln).bias)
+                        R.vector(f"{p}.{ln}.g", getattr(tb, ln).weight)
+                        R.vector(f"{p}.{ln}.b", getattr(tb, ln).bias)
                     if self.variant == "phosc":
-                        rec[p + ".a1.qkv.w"] = (lambda tb=tb: torch.cat(
-                            [tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], 0))
+                        R.matrix(p + ".a1.qkv.w", 3 * inner, inner)
+                        for i, l in enumerate((tb.attn1.to_q, tb.attn1.to_k, tb.attn1.to_v)):
+                            R[p + ".a1.qkv.w"].fwd(l.weight, row_off=i * inner)
                         cross = [("a2", tb.attn2)]
                     else:
-                        rec[p + ".a1.q.w"] = (lambda tb=tb: tb.attn1.to_q.weight)
+                        R.matrix(p + ".a1.q.w", inner, inner).fwd(tb.attn1.to_q.weight)
                         cross = [("a1", tb.attn1), ("a2", tb.attn2)]
-                    rec[p + ".a2.q.w"] = (lambda tb=tb: tb.attn2.to_q.weight)
+                    R.matrix(p + ".a2.q.w", inner, inner).fwd(tb.attn2.to_q.weight)
                     for tag, at in cross:
                         kv_w.append(at)
                         self.kv_off[f"{p}.{tag}"] = kvo
                         kvo += 2 * at.to_k.weight.shape[0]
                     for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
-                        rec[f"{p}.{tag}.o.w"] = (lambda at=at: at.to_out[0].weight)
-                        rec[f"{p}.{tag}.o.b"] = (lambda at=at: at.to_out[0].bias)
-                    rec[p + ".ff1.w"] = (lambda tb=tb: geglu_interleave(
-                        tb.ff.net[0].proj.weight, geglu_tile(tb.ff.net[2].in_features) % 1000 // 2))
-                    rec[p + ".ff1.b"] = (lambda tb=tb: geglu_interleave(
-                        tb.ff.net[0].proj.bias, geglu_tile(tb.ff.net[2].in_features) % 1000 // 2))
-                    rec[p + ".ff2.w"] = (lambda tb=tb: tb.ff.net[2].weight)
-                    rec[p + ".ff2.b"] = (lambda tb=tb: tb.ff.net[2].bias)
+                        R.linear(f"{p}.{tag}.o", at.to_out[0])
+                    ffi = tb.ff.net[2].in_features
+                    g = geglu_tile(ffi) % 1000 // 2
+                    R.matrix(p + ".ff1.w", 2 * ffi, inner).fwd(tb.ff.net[0].proj.weight, g=g)
+                    R.vector(p + ".ff1.b", tb.ff.net[0].proj.bias, g=g)
+                    R.linear(p + ".ff2", tb.ff.net[2])
         self.film_total = off
         self.kv_total = kvo
-        rec["film.w"] = lambda: torch.cat([l.weight for l in film_w], 0)
-        rec["film.b"] = lambda: torch.cat([l.bias for l in film_w], 0)
+        ted = m.time_embed[2].out_features
+        R.matrix("film.w", off, ted)
+        R.vector_cat("film.b", [l.bias for l in film_w])
+        r0 = 0
+        for l in film_w:
+            R["film.w"].fwd(l.weight, row_off=r0)
+            r0 += l.weight.shape[0]
         if kv_w:
-            rec["kv.w"] = lambda: torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in kv_w], 0)
-        rec["out.gn.g"] = lambda: m.out[0].weight
-        rec["out.gn.b"] = lambda: m.out[0].bias
-        rec["out.w"] = lambda: conv3(m.out[2].weight)
-        rec["out.b"] = lambda: m.out[2].bias
-        return rec
+            R.matrix("kv.w", kvo, kv_w[0].to_k.weight.shape[1])
+            r0 = 0
+            for at in kv_w:
+                for l in (at.to_k, at.to_v):
+                    R["kv.w"].fwd(l.weight, row_off=r0)
+                    r0 += l.weight.shape[0]
+        self._film_mods, self._kv_mods = film_w, kv_w
+        R.vector("out.gn.g", m.out[0].weight)
+        R.vector("out.gn.b", m.out[0].bias)
+        R.matrix("out.w", m.out[2].out_channels, 9 * m.out[2].in_channels).fwd(m.out[2].weight)
+        R.vector("out.b", m.out[2].bias)
+        return R
 
     def _walk(self):
         """(name, module) of every block layer in execution order."""
@@ -293,9 +392,13 @@ class UNetEngine:
             for j, mod in enumerate(blk):
                 yield f"out{i}.{j}", mod
 
-    _MATRIX_SUFFIX = (".w",)
+    def _signature(self):
+        ps = list(self.model.parameters())
+        return (sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), str(ps[0].device))
 
     def refresh_weights(self, force: bool = False):
+        """Re-derives the packed operands from the parameters when they changed (optimiser step, load_state_dict,
+        .to(device)): one ``wd_repack_multi`` launch over a device table built once per parameter placement."""
         sig = self._signature()
         if not force and sig == self._sig:
             return
@@ -311,23 +414,23 @@ class UNetEngine:
             self._tabs.clear()
             self._tab_np.clear()
             self._ws = None
+            self._pack = None
         self.device = dev
+        if self._pack is None or self._pack[0] != sig[1:]:
+            book = self._recipes()
+            for p in self.model.parameters():
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise N.NativeError("parameters must be contiguous fp32 (the reference never retypes them, unet.py:415)")
+            for name, r in book.items():
+                if name not in self._w:
+                    self._w[name] = (torch.zeros((2, r.rows, r.cols), dtype=torch.bfloat16, device=dev) if r.planes
+                                     else torch.zeros(r.shape, dtype=torch.float32, device=dev))
+            table, chunks, n = book.device_table(self.lib, self._w, dev)
+            self._pack = (sig[1:], table, chunks, n)
+        _, table, chunks, n = self._pack
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        N.check(self.lib.wd_repack_multi(table.data_ptr(), n, chunks, stream), "wd_repack_multi")
         with torch.no_grad():
-            for name, fn in self._recipes().items():
-                src = fn().detach().to(device=dev, dtype=torch.float32)
-                if name.endswith(".w"):
-                    src = src.contiguous()
-                    hi = src.to(torch.bfloat16)
-                    lo = (src - hi.float()).to(torch.bfloat16)
-                    packed = torch.stack([hi, lo], 0)
-                    if name not in self._w:
-                        self._w[name] = torch.empty_like(packed)
-                    self._w[name].copy_(packed)
-                else:
-                    src = src.contiguous()
-                    if name not in self._w:
-                        self._w[name] = torch.empty_like(src)
-                    self._w[name].copy_(src)
             for name, meta in self._w3_meta.items():
                 self._w3[name].copy_(slab_order(self._w[name], *meta))
             if "freqs" not in self._w:

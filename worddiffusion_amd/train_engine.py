@@ -24,7 +24,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _native as N
-from .backward import conv_bwd_table, pack_dx_weight
+from .backward import conv_bwd_table
 from .engine import Act, Plan, UNetEngine, _ptr
 from .layers import DownsampleParams, ResBlockParams, SpatialTransformerParams, UpsampleParams
 
@@ -66,51 +66,52 @@ class TrainEngine(UNetEngine):
 
     # ------------------------------------------------------------------------------------------ weights
     def _recipes(self):
-        rec = super()._recipes()
+        R = super()._recipes()
         m = self.model
         we = m.word_emb
-        rec["B:we.qkv.w"] = lambda: pack_dx_weight(torch.cat(
-            [we.attention.linear_query.weight, we.attention.linear_key.weight, we.attention.linear_value.weight], 0))
-        film_w, kv_w = [], []
+        cd = we.embedding.weight.shape[1]
+        R.matrix("B:we.qkv.w", cd, 3 * cd)
+        for i, l in enumerate((we.attention.linear_query, we.attention.linear_key, we.attention.linear_value)):
+            R["B:we.qkv.w"].bwd(l.weight, col_off=i * cd)
         for name, mod in self._walk():
             if isinstance(mod, ResBlockParams):
-                rec["B:" + name + ".c1.w"] = (lambda mod=mod: pack_dx_weight(mod.in_layers[2].weight))
-                rec["B:" + name + ".c2.w"] = (lambda mod=mod: pack_dx_weight(mod.out_layers[3].weight))
+                R.matrix("B:" + name + ".c1.w", mod.cin, 9 * mod.cout).bwd(mod.in_layers[2].weight)
+                R.matrix("B:" + name + ".c2.w", mod.cout, 9 * mod.cout).bwd(mod.out_layers[3].weight)
                 if mod.cin != mod.cout:
-                    rec["B:" + name + ".skip.w"] = (lambda mod=mod: pack_dx_weight(
-                        mod.skip_connection.weight.reshape(mod.cout, mod.cin)))
-                film_w.append(mod.emb_layers[1])
-            elif isinstance(mod, DownsampleParams):
-                rec["B:" + name + ".w"] = (lambda mod=mod: pack_dx_weight(mod.op.weight))
-            elif isinstance(mod, UpsampleParams):
-                rec["B:" + name + ".w"] = (lambda mod=mod: pack_dx_weight(mod.conv.weight))
+                    R.matrix("B:" + name + ".skip.w", mod.cin, mod.cout).bwd(mod.skip_connection.weight)
+            elif isinstance(mod, (DownsampleParams, UpsampleParams)):
+                conv = mod.op if isinstance(mod, DownsampleParams) else mod.conv
+                R.matrix("B:" + name + ".w", mod.cin, 9 * mod.cout).bwd(conv.weight)
             elif isinstance(mod, SpatialTransformerParams):
-                rec["B:" + name + ".pi.w"] = (lambda mod=mod: pack_dx_weight(mod.proj_in.weight.flatten(1)))
-                rec["B:" + name + ".po.w"] = (lambda mod=mod: pack_dx_weight(mod.proj_out.weight.flatten(1)))
+                inner = mod.heads * mod.d_head
+                R.matrix("B:" + name + ".pi.w", mod.ch, inner).bwd(mod.proj_in.weight)
+                R.matrix("B:" + name + ".po.w", inner, mod.ch).bwd(mod.proj_out.weight)
                 for d, tb in enumerate(mod.transformer_blocks):
                     p = f"{name}.tb{d}"
                     for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
-                        rec[f"B:{p}.{tag}.q.w"] = (lambda at=at: pack_dx_weight(at.to_q.weight))
-                        rec[f"B:{p}.{tag}.o.w"] = (lambda at=at: pack_dx_weight(at.to_out[0].weight))
-                        kv_w.append(at)
+                        R.matrix(f"B:{p}.{tag}.q.w", inner, inner).bwd(at.to_q.weight)
+                        R.matrix(f"B:{p}.{tag}.o.w", inner, inner).bwd(at.to_out[0].weight)
+                    ffi = tb.ff.net[2].in_features
                     # the training forward keeps the GEGLU pre-activation: plain [x | gate] row order (unet.py:128)
-                    rec[p + ".ff1u.w"] = (lambda tb=tb: tb.ff.net[0].proj.weight)
-                    rec[p + ".ff1u.b"] = (lambda tb=tb: tb.ff.net[0].proj.bias)
-                    rec["B:" + p + ".ff1.w"] = (lambda tb=tb: pack_dx_weight(tb.ff.net[0].proj.weight))
-                    rec["B:" + p + ".ff2.w"] = (lambda tb=tb: pack_dx_weight(tb.ff.net[2].weight))
-        rec["B:film.w"] = lambda: pack_dx_weight(torch.cat([l.weight for l in film_w], 0))
-        rec["B:kv.w"] = lambda: pack_dx_weight(torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in kv_w], 0))
-        rec["B:te2.w"] = lambda: pack_dx_weight(m.time_embed[2].weight)
-
-        def out_bw():  # C_out padded to 32 columns per tap (the gradient planes of a 4-channel map are 32 wide)
-            wt = m.out[2].weight
-            pad = wt.new_zeros(32, *wt.shape[1:])
-            pad[: wt.shape[0]] = wt
-            return pack_dx_weight(pad)
-
-        rec["B:out.w"] = out_bw
-        self._film_mods, self._kv_mods = film_w, kv_w
-        return rec
+                    R.linear(p + ".ff1u", tb.ff.net[0].proj)
+                    R.matrix("B:" + p + ".ff1.w", inner, 2 * ffi).bwd(tb.ff.net[0].proj.weight)
+                    R.matrix("B:" + p + ".ff2.w", ffi, inner).bwd(tb.ff.net[2].weight)
+        ted = m.time_embed[2].out_features
+        R.matrix("B:film.w", ted, self.film_total)
+        c0 = 0
+        for l in self._film_mods:
+            R["B:film.w"].bwd(l.weight, col_off=c0)
+            c0 += l.weight.shape[0]
+        R.matrix("B:kv.w", cd, self.kv_total)
+        c0 = 0
+        for at in self._kv_mods:
+            for l in (at.to_k, at.to_v):
+                R["B:kv.w"].bwd(l.weight, col_off=c0)
+                c0 += l.weight.shape[0]
+        R.matrix("B:te2.w", ted, ted).bwd(m.time_embed[2].weight)
+        # C_out padded to 32 columns per tap (the gradient planes of a 4-channel map are 32 wide)
+        R.matrix("B:out.w", m.out[2].in_channels, 9 * 32).bwd(m.out[2].weight, npad=32)
+        return R
 
     # ------------------------------------------------------------------------------------------ gradient buffers
     def _pgrad(self, p: torch.nn.Parameter) -> torch.Tensor:
