@@ -35,6 +35,13 @@ __global__ void adamw_multi_kernel(const TensorRef* __restrict__ tab, int ntenso
     const TensorRef t = tab[lo];
     const int64_t base = (c - t.chunk0) * CHUNK;
     const int64_t end = base + CHUNK < t.n ? base + CHUNK : t.n;
+    if (!t.g) {
+        // a parameter the loss does not reach (grad None in the reference: AdamW skips it, train.py:293); EMA still runs
+        if (t.ema && ema_mode)
+            for (int64_t i = base + threadIdx.x; i < end; i += blockDim.x)
+                t.ema[i] = ema_mode == 1 ? t.p[i] : t.ema[i] * ema_b + ema_omb * t.p[i];
+        return;
+    }
     for (int64_t i = base + threadIdx.x; i < end; i += blockDim.x) {
         const float g = t.g[i];
         float p = t.p[i] * decay;                 // param.mul_(1 - lr * weight_decay)

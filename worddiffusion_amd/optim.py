@@ -61,17 +61,16 @@ class FusedAdamW:
         recs, c0 = [], 0
         self._grads = []
         for i, p in enumerate(self.params):
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            g = g.contiguous()
+            g = p.grad.contiguous() if p.grad is not None else None  # None: torch.optim.AdamW skips the parameter
             self._grads.append(g)
             ema = self.ema_params[i].data_ptr() if self.ema_params is not None else 0
-            recs.append(struct.pack("<QQQQQqq", p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(),
+            recs.append(struct.pack("<QQQQQqq", p.data_ptr(), g.data_ptr() if g is not None else 0, self.exp_avg[i].data_ptr(),
                                     self.exp_avg_sq[i].data_ptr(), ema, p.numel(), c0))
             c0 += (p.numel() + chunk - 1) // chunk
         raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
         self._table = raw.to(self.params[0].device)
         self._chunks = c0
-        self._grad_ptrs = [g.data_ptr() for g in self._grads]
+        self._grad_ptrs = [g.data_ptr() if g is not None else 0 for g in self._grads]
 
     def step(self):
         lib = N.lib()
@@ -89,4 +88,5 @@ class FusedAdamW:
                                    self.step_count, mode, float(self.ema_beta), st), "wd_adamw_multi")
         # the kernel changed the parameters behind autograd's back: bump the version counters so that every observer
         # of Tensor._version (the engine's weight repack among them) sees the update
-        torch._C._autograd._unsafe_set_version_counter(self.params, [p._version + 1 for p in self.params])
+        touched = self.params + (self.ema_params if (self.ema_params is not None and mode) else [])
+        torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])

@@ -63,6 +63,8 @@ class TrainEngine(UNetEngine):
         self._params: Dict[int, torch.nn.Parameter] = {}
         self._btabs: Dict[tuple, torch.Tensor] = {}
         self._scr: Dict[str, torch.Tensor] = {}
+        self._arena = None
+        self._arena_used = 0
 
     # ------------------------------------------------------------------------------------------ weights
     def _recipes(self):
@@ -114,9 +116,23 @@ class TrainEngine(UNetEngine):
         return R
 
     # ------------------------------------------------------------------------------------------ gradient buffers
+    def _carve(self, shape) -> torch.Tensor:
+        """A zeroed slice of the flat gradient arena (so that data-parallel training all-reduces ONE buffer)."""
+        if self._arena is None:
+            total = sum(_rup(p.numel(), 64) for p in self.model.parameters())
+            self._arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+            self._arena_used = 0
+        n = 1
+        for d in shape:
+            n *= int(d)
+        out = self._arena[self._arena_used:self._arena_used + n].view(shape)
+        self._arena_used += _rup(n, 64)
+        assert self._arena_used <= self._arena.numel()
+        return out
+
     def _pgrad(self, p: torch.nn.Parameter) -> torch.Tensor:
         if id(p) not in self._grad:
-            self._grad[id(p)] = torch.zeros(p.shape, dtype=torch.float32, device=self.device)
+            self._grad[id(p)] = self._carve(tuple(p.shape))
             self._params[id(p)] = p
         return self._grad[id(p)]
 
@@ -127,7 +143,7 @@ class TrainEngine(UNetEngine):
         if key not in self._scr:
             tail = tuple(params[0].shape[1:])
             rows = sum(p.shape[0] for p in params)
-            buf = torch.zeros((rows,) + tail, dtype=torch.float32, device=self.device)
+            buf = self._carve((rows,) + tail)
             r0 = 0
             for p in params:
                 self._grad[id(p)] = buf[r0:r0 + p.shape[0]]
@@ -135,6 +151,10 @@ class TrainEngine(UNetEngine):
                 r0 += p.shape[0]
             self._scr[key] = buf
         return self._scr[key]
+
+    def grad_arena(self) -> torch.Tensor:
+        """All parameter gradients as one flat fp32 tensor (views of it are the ``param.grad``s)."""
+        return self._arena[: self._arena_used]
 
     def _pacc(self, t: torch.Tensor) -> int:
         """1 if the backward list has already written this parameter-gradient buffer (shared norm2), else 0."""

@@ -1,0 +1,122 @@
+"""The body of the reference's training loop (``train.py:277-294``) as a handful of device launches:
+
+    t = diffusion.sample_timesteps(B); x_t, noise = diffusion.noise_images(latents, t)        train.py:281-282
+    predicted_noise = model(x_t, ..., timesteps=t, context=text_features, y=labels)            train.py:287
+    loss = mse(noise, predicted_noise); optimizer.zero_grad(); loss.backward()                 train.py:289-291
+    optimizer.step(); ema.step_ema(ema_model, model)                                           train.py:293-294
+
+``TrainStep`` runs noise_images + forward + loss + backward as ONE hipGraph, then (data-parallel: one all-reduce of the
+flat gradient arena over RCCL) one multi-tensor AdamW+EMA launch and one weight-repack launch.  The same arithmetic is
+reachable piecewise through the reference's own call surface (``model(...)``, ``loss.backward()``, ``FusedAdamW.step``);
+this class only removes the per-step host work.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _native as N
+from .optim import FusedAdamW
+
+
+class TrainStep:
+    def __init__(self, model, diffusion, optimizer: FusedAdamW, seed: int = 0, use_graph: bool = True,
+                 process_group=None):
+        self.model, self.diffusion, self.opt = model, diffusion, optimizer
+        self.seed, self.use_graph = seed, use_graph
+        self.lib = N.lib()
+        self.eng = model.train_engine
+        self.step_index = 0
+        self._key = None
+        self._graph = None
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    def _prepare(self, B, H, W, L, dev):
+        eng = self.eng
+        eng.refresh_weights()
+        P = eng.plan_train(B, H, W, L)
+        ah = self.diffusion.alpha_hat.cpu()
+        self._sa, self._sb = torch.sqrt(ah).to(dev).contiguous(), torch.sqrt(1 - ah).to(dev).contiguous()
+        self._x0 = torch.zeros_like(P.x_in)
+        self._eps = torch.zeros_like(P.x_in)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self._P = P
+        self._stream = torch.cuda.Stream(device=dev)
+        if self._graph is not None:
+            self.lib.wd_graph_destroy(self._graph)
+            self._graph = None
+
+    def _body(self, st):
+        lib, P = self.lib, self._P
+        n = P.x_in[0].numel()
+        B = P.x_in.shape[0]
+        N.check(lib.wd_noise_images(self._x0.data_ptr(), self._eps.data_ptr(), P.t_in.data_ptr(), self._sa.data_ptr(),
+                                    self._sb.data_ptr(), B, n, P.x_in.data_ptr(), st), "wd_noise_images")
+        P.run_step(st)
+        N.check(lib.wd_mse_loss(P.out.data_ptr(), self._eps.data_ptr(), P.out.numel(), P.dout.data_ptr(), self._loss.data_ptr(),
+                                self._scratch.data_ptr(), 1024, st), "wd_mse_loss")
+        P.run_bwd(st)
+
+    def __call__(self, latents: torch.Tensor, text_features: torch.Tensor, labels: Optional[torch.Tensor],
+                 t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimisation step on a batch of latents [B, C, H, W]; returns the loss as a device tensor [1] (the
+        reference's ``loss.item()`` per step, train.py:295, is the caller's choice)."""
+        if not latents.is_cuda:
+            raise N.NativeError("TrainStep runs on the GPU only (no CPU fallback)")
+        dev = latents.device
+        B, _, H, W = latents.shape
+        key = (B, H, W, text_features.shape[1], str(dev))
+        if key != self._key:
+            self._prepare(B, H, W, text_features.shape[1], dev)
+            self._key = key
+        lib, P = self.lib, self._P
+        if t is None:
+            t = self.diffusion.sample_timesteps(B)  # host RNG like the reference (train.py:281)
+        # the legacy default stream cannot be captured: the step runs on its own stream, ordered after the caller's work
+        # and before whatever the caller enqueues next
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            st = self._stream.cuda_stream
+            P.t_in.copy_(t, non_blocking=True)
+            P.ctx_in.copy_(text_features, non_blocking=True)
+            if labels is not None:
+                P.y_in.copy_(labels, non_blocking=True)
+            self._x0.copy_(latents, non_blocking=True)
+            if noise is not None:
+                self._eps.copy_(noise, non_blocking=True)
+            else:
+                N.check(lib.wd_randn(self._eps.data_ptr(), B, self._eps[0].numel(), self.seed, self.step_index * B, 2, st),
+                        "wd_randn")
+            if self.use_graph:
+                if self._graph is None:
+                    N.check(lib.wd_graph_begin(st), "wd_graph_begin")
+                    g = C.c_void_p()
+                    try:
+                        self._body(st)
+                    finally:
+                        rc = lib.wd_graph_end(st, C.byref(g))
+                    N.check(rc, "wd_graph_end")
+                    self._graph = g
+                N.check(lib.wd_graph_launch(self._graph, st), "wd_graph_launch")
+            else:
+                self._body(st)
+            if self.world > 1:
+                arena = self.eng.grad_arena()
+                torch.distributed.all_reduce(arena, group=self.pg)  # the single gradient all-reduce of the step (RCCL/xGMI)
+                arena.mul_(1.0 / self.world)
+            self.eng.assign_grads()
+            self.opt.step()
+            self.eng.refresh_weights()
+        cur.wait_stream(self._stream)
+        for tns in (latents, text_features, labels, noise):
+            if tns is not None and tns.is_cuda:
+                tns.record_stream(self._stream)
+        self.step_index += 1
+        return self._loss
