@@ -139,6 +139,56 @@ def cpu_baseline(threads):
                        f"{dt:.3f} s/step, extrapolated to {T - 1} steps", s_per_step=dt)
 
 
+def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
+    """BASELINE configs[2]/[3]: the train.py batch loop (noise_images -> UNet -> MSE -> backward -> AdamW -> EMA) on the same
+    model and latent shape as the headline, synthetic batch resident in HBM, one gradient all-reduce per step when world > 1.
+    Reported as an extra object next to the headline metric (the headline stays the sampling throughput)."""
+    from worddiffusion_amd import Diffusion
+    from worddiffusion_amd import _native as N
+    from worddiffusion_amd.optim import FusedAdamW
+    from worddiffusion_amd.synthetic import synthetic_inputs
+    from worddiffusion_amd.training import TrainStep
+    import copy
+    model, args = build_model(dev, precision, "base")
+    model.train()
+    ema_model = copy.deepcopy(model).eval().requires_grad_(False)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, ema_model=ema_model, ema_beta=0.995, step_start_ema=2000)
+    diff = Diffusion(noise_steps=T, img_size=(64, 256), args=args)
+    step = TrainStep(model, diff, opt, seed=99 + rank)
+    inp = synthetic_inputs(B, seed=7 + rank, hw=(8, 32), num_classes=339)
+    x, ctx, y = inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev)
+    for _ in range(warmup):
+        step(x, ctx, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, ctx, y)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = wdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    ms = 1e3 * elapsed / steps
+    out = dict(workload="train.py batch loop, base UNetModel, batch %d per GPU of [4,8,32] latents, AdamW(lr 1e-4) + EMA(0.995), "
+                        "forward+loss+backward in one hipGraph" % B,
+               ms_per_step=ms, images_per_sec=world * B * 1e3 / ms, steps=steps, warmup=warmup,
+               loss_finite=bool(torch.isfinite(loss).all().item()), grad_allreduce_mb=step.eng.grad_arena().numel() * 4 / 1e6)
+    if rank == 0:
+        lib = N.lib()
+        eager = TrainStep(model, diff, opt, seed=5, use_graph=False)
+        eager(x, ctx, y)
+        torch.cuda.synchronize()
+        lib.wd_prof_enable(1)
+        eager(x, ctx, y)
+        torch.cuda.synchronize()
+        pms = (C.c_double * N.NCLASS)()
+        cnt = (C.c_int64 * N.NCLASS)()
+        fl = C.c_double()
+        lib.wd_prof_collect(pms, cnt, C.byref(fl))
+        lib.wd_prof_enable(0)
+        out["kernel_classes"] = {N.CLASS_NAMES[i]: dict(ms_per_step=pms[i], launches_per_step=int(cnt[i])) for i in range(N.NCLASS)}
+        out["gemm_tflops_algorithmic"] = fl.value / (pms[0] * 1e-3) / 1e12 if pms[0] > 0 else None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +201,7 @@ def main():
                          "(configs[4] model: 779-token context, 256-token self-attention), reported as an extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=30, help="also time this many train.py-style steps (0 = skip)")
     a = ap.parse_args()
 
     from worddiffusion_amd import dist as wdist
@@ -218,6 +269,12 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.variant == "base":
         cpu = cpu_baseline(min(os.cpu_count() or 1, 64))
 
+    train = None
+    if a.train_steps > 0 and a.variant == "base":
+        del runner
+        torch.cuda.empty_cache()
+        train = train_leg(dev, a.precision, B, a.train_steps, 5, rank, world, barrier, wdist)
+
     if rank == 0:
         value = world * B * 1e3 / (ms_per_step * (T - 1))
         line = dict(metric="denoised 64x256 word images/sec (1000-step DDPM), whole job", value=value, unit="images/s",
@@ -231,7 +288,7 @@ def main():
                                 precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
                                 images_per_sec_per_gpu=value / world, output_finite=finite),
-                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra)
+                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra, train_step=train)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

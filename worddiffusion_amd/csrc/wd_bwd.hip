@@ -64,28 +64,60 @@ __global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __res
     }
 }
 
-// ---- column sums of x[rows][ld] over row segments of `seg` rows: out[s][c] (+= when accumulate), two stages
-constexpr int CS_ROWS = 64;
+// ---- column sums of x[rows][ld] over row segments of `seg` rows: out[s][c] (+= when accumulate), two stages, fixed order
+constexpr int CS_ROWS = 128;  // rows per stage-1 workgroup: 4 row lanes x 32 rows, 64 column quads per workgroup
 __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ x, int ld, int rows, int c, int seg,
-                                                     float* __restrict__ part) {
-    // grid (ceil(seg / CS_ROWS), nseg, ceil(c / 256)); one thread per column, CS_ROWS rows per block
-    const int col = blockIdx.z * 256 + threadIdx.x;
+                                                     float* __restrict__ part, int vec) {
+    // grid (ceil(seg / CS_ROWS), nseg, ceil(c / 256)); thread = (column quad q, row lane rl)
+    __shared__ float4 red[4][64];
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.z * 256 + q * 4;
     const int s = blockIdx.y;
     const int r0 = s * seg + blockIdx.x * CS_ROWS, r1 = min(min(r0 + CS_ROWS, (s + 1) * seg), rows);
-    if (col >= c) return;
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += x[(long)r * ld + col];
-    part[((long)s * gridDim.x + blockIdx.x) * c + col] = acc;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < c) {
+        if (vec && col + 3 < c) {
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ld + col);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        } else {
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const float* p = x + (long)r * ld + col;
+                acc.x += p[0];
+                if (col + 1 < c) acc.y += p[1];
+                if (col + 2 < c) acc.z += p[2];
+                if (col + 3 < c) acc.w += p[3];
+            }
+        }
+    }
+    red[rl][q] = acc;
+    __syncthreads();
+    if (rl == 0 && col < c) {
+        const float4 a0 = red[0][q], a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
+        float* o = part + ((long)s * gridDim.x + blockIdx.x) * c + col;
+        o[0] = (a0.x + a1.x) + (a2.x + a3.x);
+        if (col + 1 < c) o[1] = (a0.y + a1.y) + (a2.y + a3.y);
+        if (col + 2 < c) o[2] = (a0.z + a1.z) + (a2.z + a3.z);
+        if (col + 3 < c) o[3] = (a0.w + a1.w) + (a2.w + a3.w);
+    }
 }
 __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ part, int nblk, int c, int nseg,
                                                      float* __restrict__ out, int out_ld, int accumulate, float scale) {
-    const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (col >= c) return;
+    // grid (ceil(c / 64), nseg); thread = (column, lane of 4 over the partial rows)
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl, s = blockIdx.y;
     double acc = 0.0;
-    for (int k = 0; k < nblk; ++k) acc += (double)part[((long)s * nblk + k) * c + col];
-    const float v = (float)acc * scale;
-    float* o = out + (long)s * out_ld + col;
-    *o = accumulate ? *o + v : v;
+    if (col < c)
+        for (int k = rl; k < nblk; k += 4) acc += (double)part[((long)s * nblk + k) * c + col];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && col < c) {
+        const float v = (float)((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * scale;
+        float* o = out + (long)s * out_ld + col;
+        *o = accumulate ? *o + v : v;
+    }
 }
 
 // ---- GroupNorm (+SiLU) backward, pass 1: per (sample, chunk, channel) sums of dy and dy * xhat,
@@ -230,7 +262,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int ld, const f
 // ---- LayerNorm backward: one wave per row; a block walks LB_ROWS rows and emits per-column partial sums of
 // dy * xhat (-> d gamma) and dy (-> d beta): colpart[blk][c][2]
 constexpr int LB_MAX4 = 8;
-constexpr int LB_ROWS = 64;
+constexpr int LB_ROWS = 16;
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy,
                                                             int dy_ld, int rows, int c, const float* __restrict__ gamma,
                                                             float eps, float* __restrict__ dx, int dx_ld, int accumulate,
@@ -330,8 +362,8 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __rest
     const int inner = heads * d;
     float* s_k = reinterpret_cast<float*>(smem);   // [nk][inner]
     float* s_v = s_k + nk * inner;                 // [nk][inner]
-    float* s_red = s_v + nk * inner;               // [tpw][inner + 4]: per-token contribution of one key
-    const int pitch = inner + 4;
+    float* s_ds = s_v + nk * inner;                // [tpw][heads][NKB]: d(score) per (token, head, key)
+    float* s_p = s_ds + tpw * heads * NKB;         // [tpw][heads][NKB]: softmax probabilities
     const int b = blockIdx.y, tid = threadIdx.x;
     const int i4 = inner >> 2;
     const int tok0 = blockIdx.x * tpw, ntok = min(tpw, nq - tok0);
@@ -403,27 +435,40 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __rest
             *reinterpret_cast<float4*>(dq + row * lddq + hoff + c * 4) = o;
         }
     }
-    // dK_j = sum_tokens ds_j q ; dV_j = sum_tokens p_j dO : one key at a time through s_red
-    float* outp = dkv_part + (((long)b * gridDim.x + blockIdx.x) * 2) * nk * inner;
-    for (int which = 0; which < 2; ++which) {
-        for (int j = 0; j < nk; ++j) {
-            __syncthreads();
-            if (act) {
-                const float w = which == 0 ? ds[j] : p[j];
-                const float* src = (which == 0 ? q + row * ldq : dout + row * ldo) + hoff;
-                for (int c = 0; c < d4; ++c) {
-                    const float4 sv = *reinterpret_cast<const float4*>(src + c * 4);
-                    *reinterpret_cast<float4*>(s_red + tl * pitch + hoff + c * 4) =
-                        make_float4(w * sv.x, w * sv.y, w * sv.z, w * sv.w);
-                }
-            }
-            __syncthreads();
-            for (int col = tid; col < inner; col += 256) {
-                float acc = 0.f;
-                for (int t = 0; t < ntok; ++t) acc += s_red[t * pitch + col];
-                outp[((long)j * 2 + which) * inner + col] = acc;
-            }
+    // dK_j = sum_tokens ds_j q ; dV_j = sum_tokens p_j dO: the per-(token, head) coefficients go through LDS, then one thread
+    // per output column accumulates all keys over the workgroup's tokens in a fixed order
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+        if (tl < tpw) {
+            s_ds[(tl * heads + h) * NKB + j] = act ? ds[j] : 0.f;
+            s_p[(tl * heads + h) * NKB + j] = act ? p[j] : 0.f;
         }
+    }
+    __syncthreads();
+    float* outp = dkv_part + (((long)b * gridDim.x + blockIdx.x) * 2) * nk * inner;
+    const long row0 = (long)b * nq + tok0;
+    for (int col = tid; col < inner; col += 256) {
+        const int hh = col / d;
+        float ak[NKB], av[NKB];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) ak[j] = av[j] = 0.f;
+        for (int t = 0; t < ntok; ++t) {
+            const float qv = q[(row0 + t) * ldq + col], gv = dout[(row0 + t) * ldo + col];
+            const float* cds = s_ds + (t * heads + hh) * NKB;
+            const float* cp = s_p + (t * heads + hh) * NKB;
+#pragma unroll
+            for (int j = 0; j < NKB; ++j)
+                if (j < nk) {
+                    ak[j] += cds[j] * qv;
+                    av[j] += cp[j] * gv;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                outp[((long)j * 2 + 0) * inner + col] = ak[j];
+                outp[((long)j * 2 + 1) * inner + col] = av[j];
+            }
     }
 }
 
@@ -545,8 +590,9 @@ extern "C" int wd_colsum(const float* x, int ld, int rows, int c, int seg, float
     if ((int64_t)nseg * nblk * c > scratch_floats) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
-    hipLaunchKernelGGL(colsum_stage1, dim3(nblk, nseg, (c + 255) / 256), dim3(256), 0, st, x, ld, rows, c, seg, scratch);
-    hipLaunchKernelGGL(colsum_stage2, dim3((c + 255) / 256, nseg), dim3(256), 0, st, scratch, nblk, c, nseg, out, out_ld,
+    const int vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    hipLaunchKernelGGL(colsum_stage1, dim3(nblk, nseg, (c + 255) / 256), dim3(256), 0, st, x, ld, rows, c, seg, scratch, vec);
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 63) / 64, nseg), dim3(256), 0, st, scratch, nblk, c, nseg, out, out_ld,
                        accumulate, scale);
     return wd_check_launch();
 }
@@ -599,12 +645,9 @@ extern "C" int wd_layernorm_bwd(const float* x, int ld, const float* dy, int dy_
 static int attn_bwd_tpw(int heads, int nq, int nk, int d) {
     const int inner = heads * d;
     int tpw = 256 / heads;
-    const long budget = (long)150 * 1024 / 4 - (long)2 * nk * inner;
-    if (budget <= 0) return 0;
-    const long fit = budget / (inner + 4);
-    if (fit < tpw) tpw = (int)fit;
     if (nq < tpw) tpw = nq;
-    return tpw;
+    const long floats = (long)2 * nk * inner + (long)2 * tpw * heads * NKB;
+    return floats * 4 <= 150 * 1024 ? tpw : 0;
 }
 
 extern "C" int wd_attention_bwd_small_nwg(int heads, int nq, int nk, int d) {
@@ -621,7 +664,7 @@ extern "C" int wd_attention_bwd_small(const float* q, int ldq, const float* k, i
     if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddq % 4) return WD_EINVAL;
     const int inner = heads * d, tpw = attn_bwd_tpw(heads, nq, nk, d);
     if (tpw <= 0) return WD_EINVAL;
-    const size_t smem = ((size_t)2 * nk * inner + (size_t)tpw * (inner + 4)) * sizeof(float);
+    const size_t smem = ((size_t)2 * nk * inner + (size_t)2 * tpw * heads * NKB) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static size_t set = 64 * 1024;
     if (smem > set) {

@@ -152,6 +152,17 @@ class TrainEngine(UNetEngine):
             self._scr[key] = buf
         return self._scr[key]
 
+    def _ppair(self, p0: torch.nn.Parameter, p1: torch.nn.Parameter) -> torch.Tensor:
+        """[2, c] buffer: row 0 is p0's gradient, row 1 p1's (norm scale / shift pairs come out of one column sum)."""
+        key = ("pair", id(p0), id(p1))
+        if key not in self._scr:
+            buf = self._carve((2,) + tuple(p0.shape))
+            for i, p in enumerate((p0, p1)):
+                self._grad[id(p)] = buf[i]
+                self._params[id(p)] = p
+            self._scr[key] = buf
+        return self._scr[key]
+
     def grad_arena(self) -> torch.Tensor:
         """All parameter gradients as one flat fp32 tensor (views of it are the ``param.grad``s)."""
         return self._arena[: self._arena_used]
@@ -263,11 +274,17 @@ class TrainEngine(UNetEngine):
                 self._pacc(dst)
             else:
                 self._gemm_dw(ops, f"{what}:dW{si}", doutT, n, xT, k, mpad, wg, k, self._pacc(wg))
-        for b in bias:
-            self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
         if film_off is not None:
+            # per-sample column sums are the FiLM gradient; summing those over the batch is the bias gradient
+            B = M // hw_out
             self._colsum(ops, what + ":dfilm", dout.data_ptr(), ldd, M, n, hw_out,
                          self._dfilm.data_ptr() + 4 * film_off, self.film_total, 0)
+            for b in bias:
+                self._colsum(ops, what + ":dbias", self._dfilm.data_ptr() + 4 * film_off, self.film_total, B, n, B,
+                             b.data_ptr(), n, self._pacc(b))
+        else:
+            for b in bias:
+                self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
 
     def _gn_bwd(self, P, what, srcs: List[TAct], gn: torch.nn.GroupNorm, eps, silu, dz: torch.Tensor):
         ops = P.bwd
@@ -278,11 +295,11 @@ class TrainEngine(UNetEngine):
         cpg = ctot // 32
         gam, bet = gn.weight, gn.bias
         gw, gb = self._w[self._gn_names[id(gn)] + ".g"], self._w[self._gn_names[id(gn)] + ".b"]
-        dgam, dbet = self._pgrad(gam), self._pgrad(bet)
+        pair = self._ppair(bet, gam)  # [d beta | d gamma], the order of the planar sums
+        dbet, dgam = pair[0], pair[1]
         nb = lib.wd_gn_bwd_nchunk(hw)
         off = 0
-        accp = self._pacc(dgam)
-        self._pacc(dbet)
+        accp = self._pacc(pair)
         for s in srcs:
             part, nchunk, pc = s.stats
             sums = self._f32(P, B, nb, 2, s.c)
@@ -291,10 +308,14 @@ class TrainEngine(UNetEngine):
             ops.append((lib.wd_gn_bwd_stats, common, what + ":stats"))
             g, acc = self._gacc(P, s)
             ops.append((lib.wd_gn_bwd_apply, common + (g.data_ptr(), s.c, acc), what + ":apply"))
-            self._colsum(ops, what + ":dbeta", sums.data_ptr(), 2 * s.c, B * nb, s.c, B * nb, dbet.data_ptr() + 4 * off,
-                         s.c, accp)
-            self._colsum(ops, what + ":dgamma", sums.data_ptr() + 4 * s.c, 2 * s.c, B * nb, s.c, B * nb,
-                         dgam.data_ptr() + 4 * off, s.c, accp)
+            if len(srcs) == 1:
+                self._colsum(ops, what + ":dbeta|dgamma", sums.data_ptr(), 2 * s.c, B * nb, 2 * s.c, B * nb, pair.data_ptr(),
+                             2 * s.c, accp)
+            else:
+                self._colsum(ops, what + ":dbeta", sums.data_ptr(), 2 * s.c, B * nb, s.c, B * nb, dbet.data_ptr() + 4 * off,
+                             s.c, accp)
+                self._colsum(ops, what + ":dgamma", sums.data_ptr() + 4 * s.c, 2 * s.c, B * nb, s.c, B * nb,
+                             dgam.data_ptr() + 4 * off, s.c, accp)
             off += s.c
 
     def _ln_bwd(self, P, what, x: torch.Tensor, rows, c, ln: torch.nn.LayerNorm, name, dy: torch.Tensor, dx: torch.Tensor,
@@ -305,11 +326,9 @@ class TrainEngine(UNetEngine):
         colpart = self._f32(P, nblk, 2, c)
         ops.append((lib.wd_layernorm_bwd, (x.data_ptr(), c, dy.data_ptr(), c, rows, c, self._w[name + ".g"].data_ptr(), 1e-5,
                                            dx.data_ptr(), c, int(acc), colpart.data_ptr()), what))
-        dg, db = self._pgrad(ln.weight), self._pgrad(ln.bias)
-        accp = self._pacc(dg)
-        self._pacc(db)
-        self._colsum(ops, what + ":dgamma", colpart.data_ptr(), 2 * c, nblk, c, nblk, dg.data_ptr(), c, accp)
-        self._colsum(ops, what + ":dbeta", colpart.data_ptr() + 4 * c, 2 * c, nblk, c, nblk, db.data_ptr(), c, accp)
+        pair = self._ppair(ln.weight, ln.bias)  # [d gamma | d beta], the order of colpart
+        self._colsum(ops, what + ":dgamma|dbeta", colpart.data_ptr(), 2 * c, nblk, 2 * c, nblk, pair.data_ptr(), 2 * c,
+                     self._pacc(pair))
 
     def _attn_bwd(self, P, what, q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO: torch.Tensor, heads, nq, nk, d, scale, dq_ptr, lddq,
                   dkv_ptr, dkv_pitch_floats):
