@@ -256,8 +256,19 @@ def main():
             lib.wd_prof_enable(0)
         gemm_ms, gemm_n, gemm_flops = ms[0], cnt[0], fl.value
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/, per round)
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                              "r01_pmc_hbm_traffic.json")))
+            k = pmc["wd_gemm2_kernel<128, 160, 3, 2>"]
+            traffic = (k["fetch_mb_corrected"] + k["write_mb"]) * 1e6
+            traffic_note = ("HBM bytes per launch of wd_gemm2_kernel<128,160,3,2>: %.1f MB fetched (FETCH_SIZE, gfx950 x2 "
+                            "correction) + %.1f MB written (WRITE_SIZE); separate rocprofv3 --pmc passes over this bench "
+                            "command, profiles/r01_pmc_hbm_traffic.json" % (k["fetch_mb_corrected"], k["write_mb"]))
+        except (OSError, KeyError, ValueError):
+            traffic, traffic_note = None, "no PMC summary under profiles/"
         roof = dict(bound="mfma", kernel="wd_gemm_kernel<BM,BN,NPASS> (tap-gather MFMA GEMM, all conv/linear layers)",
-                    achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+                    achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_note=traffic_note,
                     launches_per_step=gemm_n // nprof, avg_launch_us=1e3 * gemm_ms / max(gemm_n, 1),
                     algorithmic_gflop_per_step=gemm_flops / nprof / 1e9,
                     mfma_issue_factor=3 if a.precision == "bf16x3" else 1,
