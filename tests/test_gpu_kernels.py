@@ -333,7 +333,8 @@ def test_layernorm_and_split():
 
 @pytest.mark.parametrize("B,H,nq,nk,d,scale", [(3, 4, 256, 10, 80, 80 ** -0.5), (2, 4, 64, 64, 16, 0.25),
                                                (2, 1, 10, 10, 320, 1.0), (2, 4, 70, 779, 80, 80 ** -0.5),
-                                               (1, 1, 769, 769, 64, 1.0)])
+                                               (1, 1, 769, 769, 64, 1.0), (2, 4, 256, 256, 80, 80 ** -0.5),
+                                               (2, 2, 100, 33, 32, 0.3), (1, 3, 40, 200, 96, 0.1), (1, 2, 129, 65, 48, 0.2)])
 def test_attention(B, H, nq, nk, d, scale):
     lib = N.lib()
     g = torch.Generator().manual_seed(nq + nk + d)

@@ -210,6 +210,205 @@ __global__ void __launch_bounds__(256) attn_small_kernel(const float* __restrict
     }
 }
 
+
+// ---- MFMA attention (spatial self-attention of the PHOSC UNet, its 779-token cross-attention; unetPhosc.py:157-198) -------
+// One workgroup = 128 queries of one (sample, head); each of its 4 waves owns 32 queries.  Per 32-key block:
+//   S^T[key][query] = K . Q^T on v_mfma_f32_32x32x16_bf16: a lane then holds ONE query (column lane & 31) and 16 keys in
+//   its accumulator registers, so the softmax statistics are per-lane scalars (one cross-half exchange);
+//   O^T[dv][query] += V^T . P^T with the accumulator registers themselves as the B operand: the MFMA reduction index is
+//   only a label, so V^T is stored in LDS with the keys permuted to the order the S^T accumulator delivers them.
+// Operands are split-bf16 (hi + lo, three MFMAs per product) like the GEMM: results stay at fp32-class accuracy.
+typedef __attribute__((ext_vector_type(8))) __bf16 fa_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float fa_f32x16;
+constexpr int FA_KB = 64;    // keys per LDS block (two 32-key MFMA sub-blocks)
+constexpr int FA_QB = 128;   // queries per workgroup
+
+__device__ __forceinline__ void fa_split8(const float* f, fa_bf16x8& hi, fa_bf16x8& lo) {
+    uint2 h0, l0, h1, l1;
+    wd_split4(make_float4(f[0], f[1], f[2], f[3]), h0, l0);
+    wd_split4(make_float4(f[4], f[5], f[6], f[7]), h1, l1);
+    const uint4 hv = make_uint4(h0.x, h0.y, h1.x, h1.y), lv = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    hi = *reinterpret_cast<const fa_bf16x8*>(&hv);
+    lo = *reinterpret_cast<const fa_bf16x8*>(&lv);
+}
+
+template <int KS, int DVT>
+__global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                        int ldk, const float* __restrict__ v, int ldv, int heads, int nq,
+                                                        int nk, float scale, float* __restrict__ out_f32,
+                                                        wd_bf16* __restrict__ out_hi, wd_bf16* __restrict__ out_lo, int out_ld,
+                                                        int out_rows, int out_row0) {
+    constexpr int D = KS * 16;
+    constexpr int KP = D + 8;        // sK row pitch (bf16 elements): 16-byte fragment reads, rows spread over the banks
+    constexpr int VP = FA_KB + 8;    // sVt row pitch
+    constexpr int DVR = DVT * 32;    // V^T rows (dv padded to whole 32-row MFMA tiles; the padding rows stay zero)
+    constexpr int OP = D + 4;        // fp32 output staging pitch
+    constexpr int D4 = D / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wd_bf16* sK = reinterpret_cast<wd_bf16*>(smem);   // [2 planes][FA_KB][KP]
+    wd_bf16* sV = sK + 2 * FA_KB * KP;                // [2 planes][DVR][VP]
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // Q fragments (B operand of S^T = K . Q^T), scaled by softmax_scale * log2(e) so that the exponentials are exp2
+    fa_bf16x8 qh[KS], ql[KS];
+    {
+        const int qi = q0 + wave * 32 + l31;
+        const float sc = scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float f[8];
+            if (qi < nq) {
+                const float* p = q + ((long)b * nq + qi) * ldq + h * D + ks * 16 + lh * 8;
+                const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+                f[0] = a.x * sc; f[1] = a.y * sc; f[2] = a.z * sc; f[3] = a.w * sc;
+                f[4] = c.x * sc; f[5] = c.y * sc; f[6] = c.z * sc; f[7] = c.w * sc;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
+            }
+            fa_split8(f, qh[ks], ql[ks]);
+        }
+    }
+    if constexpr (DVR > D) {  // zero the dv padding rows of both planes once
+        constexpr int PADN = (DVR - D) * VP;
+        for (int e = tid; e < 2 * PADN; e += 256) {
+            const int pl = e / PADN, r = e - pl * PADN;
+            sV[(pl * DVR + D) * VP + r] = 0;
+        }
+    }
+    fa_f32x16 o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+
+    for (int kb = 0; kb < nk; kb += FA_KB) {
+        __syncthreads();  // the previous block has been consumed
+        for (int e = tid; e < FA_KB * D4; e += 256) {
+            const int key = e / D4, c4 = e - key * D4;
+            const int gk = kb + key;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (gk < nk) {
+                kv = *reinterpret_cast<const float4*>(k + ((long)b * nk + gk) * ldk + h * D + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(v + ((long)b * nk + gk) * ldv + h * D + c4 * 4);
+            }
+            uint2 hi, lo;
+            wd_split4(kv, hi, lo);
+            *reinterpret_cast<uint2*>(sK + (long)key * KP + c4 * 4) = hi;
+            *reinterpret_cast<uint2*>(sK + (long)(FA_KB + key) * KP + c4 * 4) = lo;
+            // V^T with the keys of each 32-block in accumulator order: position = key with bits 2 and 3 swapped
+            const int kl = key & 31;
+            const int pos = (key & 32) | (kl & 0x13) | ((kl & 4) << 1) | ((kl & 8) >> 1);
+            wd_split4(vv, hi, lo);
+            wd_bf16* vh = sV + (long)(c4 * 4) * VP + pos;
+            wd_bf16* vl = sV + (long)(DVR + c4 * 4) * VP + pos;
+            vh[0] = (wd_bf16)(hi.x & 0xffff); vh[VP] = (wd_bf16)(hi.x >> 16);
+            vh[2 * VP] = (wd_bf16)(hi.y & 0xffff); vh[3 * VP] = (wd_bf16)(hi.y >> 16);
+            vl[0] = (wd_bf16)(lo.x & 0xffff); vl[VP] = (wd_bf16)(lo.x >> 16);
+            vl[2 * VP] = (wd_bf16)(lo.y & 0xffff); vl[3 * VP] = (wd_bf16)(lo.y >> 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < FA_KB / 32; ++sub) {
+            const int k0 = kb + sub * 32;
+            if (k0 >= nk) break;  // uniform over the workgroup
+            fa_f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const wd_bf16* kp = sK + (long)(sub * 32 + l31) * KP + ks * 16 + lh * 8;
+                const fa_bf16x8 ah = *reinterpret_cast<const fa_bf16x8*>(kp);
+                const fa_bf16x8 al = *reinterpret_cast<const fa_bf16x8*>(kp + FA_KB * KP);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
+            }
+            float bm = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= nk) s[r] = -1e30f;
+                bm = fmaxf(bm, s[r]);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float m_new = fmaxf(m, bm);
+            const float alpha = exp2f(m - m_new);
+            m = m_new;
+            lsum *= alpha;
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = exp2f(s[r] - m_new);
+                lsum += p[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa_bf16x8 ph, pl;
+                fa_split8(p + 8 * i, ph, pl);
+#pragma unroll
+                for (int t = 0; t < DVT; ++t) {
+                    const wd_bf16* vp = sV + (long)(t * 32 + l31) * VP + sub * 32 + i * 16 + lh * 8;
+                    const fa_bf16x8 ah = *reinterpret_cast<const fa_bf16x8*>(vp);
+                    const fa_bf16x8 al = *reinterpret_cast<const fa_bf16x8*>(vp + DVR * VP);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    __syncthreads();
+    float* sO = reinterpret_cast<float*>(smem);  // [FA_QB][OP]
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (dv < D) sO[(wave * 32 + l31) * OP + dv] = o[t][r] * inv;
+        }
+    __syncthreads();
+    for (int e = tid; e < FA_QB * D4; e += 256) {
+        const int qlr = e / D4, c4 = e - qlr * D4;
+        const int qi = q0 + qlr;
+        if (qi >= nq) continue;
+        const float4 val = *reinterpret_cast<const float4*>(sO + qlr * OP + c4 * 4);
+        const long orow = (long)b * out_rows + out_row0 + qi;
+        const long off = orow * out_ld + h * D + c4 * 4;
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + off) = val;
+        if (out_hi) {
+            uint2 hi, lo;
+            wd_split4(val, hi, lo);
+            *reinterpret_cast<uint2*>(out_hi + off) = hi;
+            if (out_lo) *reinterpret_cast<uint2*>(out_lo + off) = lo;
+        }
+    }
+}
+
+template <int KS, int DVT>
+static int launch_attn_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int batch, int heads,
+                            int nq, int nk, float scale, float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld,
+                            int out_rows, int out_row0, hipStream_t st) {
+    constexpr int D = KS * 16;
+    constexpr size_t tiles = (size_t)(2 * FA_KB * (D + 8) + 2 * DVT * 32 * (FA_KB + 8)) * sizeof(wd_bf16);
+    constexpr size_t stage = (size_t)FA_QB * (D + 4) * sizeof(float);
+    constexpr size_t smem = tiles > stage ? tiles : stage;
+    static_assert(smem <= 64 * 1024, "attention tile does not fit the default dynamic LDS limit");
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT>), dim3((nq + FA_QB - 1) / FA_QB, heads, batch), dim3(256), smem, st, q, ldq, k,
+                       ldk, v, ldv, heads, nq, nk, scale, out_f32, out_hi, out_lo, out_ld, out_rows, out_row0);
+    return wd_check_launch();
+}
+
 }  // namespace
 
 extern "C" int wd_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int batch,
@@ -247,6 +446,21 @@ extern "C" int wd_attention(const float* q, int ldq, const float* k, int ldk, co
                                    out_row0, tpw);
             return wd_check_launch();
         }
+    }
+    if (nk > NKS && d % 16 == 0 && d <= 96 && out_ld % 4 == 0 && !getenv("WDIFF_ATTN_GENERIC")) {
+        // spatial self-attention / long-context cross-attention: MFMA kernel (split-bf16, fp32 softmax)
+#define WD_FA(KS_, DVT_)                                                                                            \
+    return launch_attn_mfma<KS_, DVT_>(q, ldq, k, ldk, v, ldv, batch, heads, nq, nk, scale, out_f32, out_hi, out_lo, \
+                                       out_ld, out_rows, out_row0, st)
+        switch (d / 16) {
+            case 1: WD_FA(1, 1);
+            case 2: WD_FA(2, 1);
+            case 3: WD_FA(3, 2);
+            case 4: WD_FA(4, 2);
+            case 5: WD_FA(5, 3);
+            case 6: WD_FA(6, 3);
+        }
+#undef WD_FA
     }
     static size_t max_set = 64 * 1024;
     if (smem > max_set) {
