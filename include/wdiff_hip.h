@@ -249,6 +249,14 @@ int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, con
                            int ldo, int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq,
                            float* dkv_part, int* nwg_out, void* stream);
 
+/* Attention backward for any number of keys <= 1024 (spatial self-attention, the 779-token PHOSC context): recomputes the
+ * softmax rows, dq/dk/dv written in place of autograd's (row pitches ldd*; head h owns columns [h*d, (h+1)*d)).
+ * scratch: wd_attention_bwd_scratch_floats() floats (P and dS, [batch][heads][nq][nk] each).  Deterministic. */
+int64_t wd_attention_bwd_scratch_floats(int batch, int heads, int nq, int nk);
+int wd_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout, int ldo,
+                     int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq, float* dk, int lddk,
+                     float* dv, int lddv, float* scratch, int64_t scratch_floats, void* stream);
+
 /* dst[i] += src[i] (gradient accumulation where a feature map has several consumers: residual adds, the skip stack
  * of unet.py:1750). 16-byte aligned pointers. */
 int wd_add(float* dst, const float* src, int64_t n, void* stream);

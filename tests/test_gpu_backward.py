@@ -249,3 +249,53 @@ def test_geglu_silu_pool_embedding_backward():
     N.check(lib.wd_embedding_bwd(idd.data_ptr(), 1, 6, ddd.data_ptr(), 40, 11, 40, dt.data_ptr(), 1, _st()), "emb bwd")
     torch.cuda.synchronize()
     assert max_rel(dt.cpu() - 2.0, table.grad) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,nq,nk,d,scale,self_attn", [(2, 4, 32, 32, 16, 0.25, True), (2, 4, 256, 256, 80, 80 ** -0.5, True),
+                                                          (1, 4, 70, 779, 80, 80 ** -0.5, False), (1, 1, 130, 130, 320, 1.0, True),
+                                                          (2, 2, 50, 10, 32, 0.2, False)])
+def test_attention_backward_generic(B, H, nq, nk, d, scale, self_attn):
+    """wd_attention_bwd (any key count) vs autograd; self-attention reads q, k, v out of one [M, 3*inner] buffer and writes
+    d(qkv) the same way (the PHOSC UNet's attn1, unetPhosc.py:241)."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(nq * 3 + nk)
+    inner = H * d
+    if self_attn:
+        qkv = torch.randn(B * nq, 3 * inner, generator=g) * 0.5
+        q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    else:
+        q = torch.randn(B * nq, inner, generator=g) * 0.5
+        kv = torch.randn(B * nk, 2 * inner, generator=g) * 0.5
+        k, v = kv[:, :inner], kv[:, inner:]
+    do = torch.randn(B * nq, inner, generator=g)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+
+    def heads(t, n):
+        return t.reshape(B, n, H, d).permute(0, 2, 1, 3)
+
+    att = torch.softmax(heads(qr, nq) @ heads(kr, nk).transpose(-1, -2) * scale, -1)
+    (att @ heads(vr, nk)).permute(0, 2, 1, 3).reshape(B * nq, inner).backward(do.double())
+    dod = do.to(DEV)
+    nscr = lib.wd_attention_bwd_scratch_floats(B, H, nq, nk)
+    scr = torch.empty(nscr, device=DEV)
+    if self_attn:
+        src = qkv.to(DEV)
+        dst = torch.zeros(B * nq, 3 * inner, device=DEV)
+        ld = 3 * inner
+        N.check(lib.wd_attention_bwd(src.data_ptr(), ld, src.data_ptr() + 4 * inner, ld, src.data_ptr() + 8 * inner, ld,
+                                     dod.data_ptr(), inner, B, H, nq, nk, d, scale, dst.data_ptr(), ld,
+                                     dst.data_ptr() + 4 * inner, ld, dst.data_ptr() + 8 * inner, ld, scr.data_ptr(), nscr, _st()),
+                "attn bwd")
+        torch.cuda.synchronize()
+        got = dst.cpu()
+        dq, dk, dv = got[:, :inner], got[:, inner:2 * inner], got[:, 2 * inner:]
+    else:
+        qd, kvd = q.contiguous().to(DEV), kv.to(DEV)
+        dq = torch.zeros(B * nq, inner, device=DEV)
+        dkv = torch.zeros(B * nk, 2 * inner, device=DEV)
+        N.check(lib.wd_attention_bwd(qd.data_ptr(), inner, kvd.data_ptr(), 2 * inner, kvd.data_ptr() + 4 * inner, 2 * inner,
+                                     dod.data_ptr(), inner, B, H, nq, nk, d, scale, dq.data_ptr(), inner, dkv.data_ptr(),
+                                     2 * inner, dkv.data_ptr() + 4 * inner, 2 * inner, scr.data_ptr(), nscr, _st()), "attn bwd")
+        torch.cuda.synchronize()
+        dq, dk, dv = dq.cpu(), dkv.cpu()[:, :inner], dkv.cpu()[:, inner:]
+    assert max_rel(dq, qr.grad) < 3e-5 and max_rel(dk, kr.grad) < 3e-5 and max_rel(dv, vr.grad) < 3e-5

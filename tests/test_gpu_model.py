@@ -436,3 +436,77 @@ def test_train_step_device_noise_and_timesteps():
     assert np.isfinite(last) and last < 0.7 * first, (first, last)
     l2 = float(step(x, c, y).cpu())
     assert np.isfinite(l2)
+
+
+def test_train_step_matches_reference_golden(golden_dir):
+    """The reference's own train step (tests/golden/train_step.npz: train.py:287-294 run on UNetModelPhosc with MSELoss,
+    loss.backward(), AdamW(lr 1e-4), EMA) against the HIP path: prediction, loss, the recorded gradients (convs, attention
+    projections, GEGLU, embeddings, word-encoder), the AdamW-updated tensors."""
+    from worddiffusion_amd.optim import FusedAdamW
+    g = load_golden(golden_dir, "train_step")
+    m = UNetModelPhosc(args=make_args(device=DEV), **SMALL)
+    fill_module_(m, int(g["seed_model"]))
+    m = m.to(DEV).train()
+    opt = FusedAdamW(m.parameters(), lr=1e-4)
+    pred = m(torch.from_numpy(g["x_t"]).to(DEV), None, timesteps=torch.from_numpy(g["t"]).to(DEV),
+             context=torch.from_numpy(g["context"]).to(DEV), y=torch.from_numpy(g["y"]).to(DEV))
+    loss = torch.nn.MSELoss()(torch.from_numpy(g["eps"]).to(DEV), pred)
+    opt.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert max_rel(pred.detach().cpu(), g["pred"]) < 5e-5
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    params = dict(m.named_parameters())
+    gsq = 0.0
+    for k, p in params.items():
+        if p.grad is not None:
+            gsq += float((p.grad.double() ** 2).sum())
+    assert abs(gsq ** 0.5 - float(g["grad_norm"])) < 2e-4 * float(g["grad_norm"])
+    for name in g.files:
+        if name.startswith("grad:"):
+            k = name[5:]
+            ref = torch.from_numpy(g[name]).double()
+            err = float((params[k].grad.detach().cpu().double() - ref).norm())
+            assert err < 2e-4 * float(ref.norm()) + 1e-7, (k, err, float(ref.norm()))
+    opt.step()
+    torch.cuda.synchronize()
+    for name in g.files:
+        if name.startswith("adamw:"):
+            k = name[6:]
+            # first Adam step: +-lr per coordinate; coordinates with |g| ~ 1e-8 may differ in sign -> norm-wise check
+            ref = torch.from_numpy(g[name]).double()
+            got = params[k].detach().cpu().double()
+            assert float((got - ref).norm()) < 0.02 * 1e-4 * ref.numel() ** 0.5, k
+
+
+@pytest.mark.parametrize("cfg_name,B,hw,phosc_len", [("SMALL", 2, (4, 8), 769), ("DEEP", 2, (8, 16), 40), ("FULL", 1, (8, 32), 0)])
+def test_phosc_training_gradients_match_oracle_autograd(cfg_name, B, hw, phosc_len):
+    """UNetModelPhosc train step (spatial self-attention, PHOSC tokens in the context) vs oracle autograd, all gradients."""
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    cfg = {"SMALL": SMALL, "DEEP": DEEP, "FULL": FULL}[cfg_name]
+    seed = 55
+    inp = synthetic_inputs(B, seed=21, hw=hw, num_classes=cfg["num_classes"], phosc_len=phosc_len)
+    eps = torch.from_numpy(np.random.RandomState(3).standard_normal(tuple(inp["x"].shape)).astype(np.float32))
+    shapes = U.state_dict_shapes(cfg, "phosc")
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, seed)).requires_grad_(True) for k, s in shapes}
+    orc = U.UNetOracle(cfg, sd, "phosc", phosc_len > 0)
+    pred_ref = orc(inp["x"], inp["t"], inp["context"], inp["y"], inp.get("phosc"))
+    torch.nn.functional.mse_loss(pred_ref, eps).backward()
+    m = UNetModelPhosc(args=make_args(device=DEV, phosc=1 if phosc_len else 0), **cfg)
+    fill_module_(m, seed)
+    m = m.to(DEV).train()
+    pred = m(inp["x"].to(DEV), inp["phosc"].to(DEV) if phosc_len else None, timesteps=inp["t"].to(DEV),
+             context=inp["context"].to(DEV), y=inp["y"].to(DEV))
+    torch.nn.MSELoss()(eps.to(DEV), pred).backward()
+    torch.cuda.synchronize()
+    assert max_rel(pred.detach().cpu(), pred_ref.detach()) < 5e-5
+    params = dict(m.named_parameters())
+    for k, ref in sd.items():
+        gr = params[k].grad
+        if ref.grad is None:
+            assert gr is None, k
+            continue
+        assert gr is not None, k
+        r = ref.grad.double()
+        err = float((gr.detach().cpu().double() - r).norm())
+        assert err < 2e-4 * float(r.norm()) + 1e-7, (k, err, float(r.norm()))

@@ -472,6 +472,121 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __rest
     }
 }
 
+
+// ---- attention backward, any number of keys (spatial self-attention / the 779-token PHOSC context; unetPhosc.py:157-198).
+// Pass 1, one wave per query row: recompute the softmax row, write P and dS (scaled) to scratch, and dq.
+// Pass 2, one wave per key: dK_j = sum_i dS_ij q_i, dV_j = sum_i P_ij dO_i in query order (deterministic, no partials).
+constexpr int AG_NJ = 16;  // keys per lane: up to 64 * 16 = 1024 keys
+__global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                            int ldk, const float* __restrict__ v, int ldv,
+                                                            const float* __restrict__ dout, int ldo, int heads, int nq, int nk,
+                                                            int d, float scale, float* __restrict__ dq, int lddq,
+                                                            float* __restrict__ pbuf, float* __restrict__ dsbuf,
+                                                            long total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_q = reinterpret_cast<float*>(smem) + wave * (2 * d + nk);  // [d] q row, [d] dO row, [nk] dS row
+    float* s_g = s_q + d;
+    float* s_ds = s_g + d;
+    const long rowid = (long)blockIdx.x * 4 + wave;                     // (b * heads + h) * nq + i
+    if (rowid >= total) return;
+    const int i = (int)(rowid % nq);
+    const int h = (int)((rowid / nq) % heads);
+    const int b = (int)(rowid / ((long)nq * heads));
+    const float* qr = q + ((long)b * nq + i) * ldq + h * d;
+    const float* gr = dout + ((long)b * nq + i) * ldo + h * d;
+    for (int c = lane; c < d; c += 64) {
+        s_q[c] = qr[c];
+        s_g[c] = gr[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sc[AG_NJ], dp[AG_NJ];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int t = 0; t < AG_NJ; ++t) {
+        const int j = lane + 64 * t;
+        sc[t] = -3.4e38f;
+        dp[t] = 0.f;
+        if (j < nk) {
+            const float* kr = k + ((long)b * nk + j) * ldk + h * d;
+            const float* vr = v + ((long)b * nk + j) * ldv + h * d;
+            float a = 0.f, g = 0.f;
+            for (int c = 0; c < d; c += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + c), vv = *reinterpret_cast<const float4*>(vr + c);
+                a += s_q[c] * kv.x + s_q[c + 1] * kv.y + s_q[c + 2] * kv.z + s_q[c + 3] * kv.w;
+                g += s_g[c] * vv.x + s_g[c + 1] * vv.y + s_g[c + 2] * vv.z + s_g[c + 3] * vv.w;
+            }
+            sc[t] = a * scale;
+            dp[t] = g;
+            mx = fmaxf(mx, sc[t]);
+        }
+    }
+    mx = wd_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < AG_NJ; ++t) {
+        const int j = lane + 64 * t;
+        sc[t] = j < nk ? expf(sc[t] - mx) : 0.f;
+        sum += sc[t];
+    }
+    const float inv = 1.f / wd_wave_sum(sum);
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < AG_NJ; ++t) {
+        sc[t] *= inv;
+        dot += sc[t] * dp[t];
+    }
+    dot = wd_wave_sum(dot);
+    float* prow = pbuf + rowid * nk;
+    float* dsrow = dsbuf + rowid * nk;
+#pragma unroll
+    for (int t = 0; t < AG_NJ; ++t) {
+        const int j = lane + 64 * t;
+        if (j < nk) {
+            const float ds = sc[t] * (dp[t] - dot) * scale;
+            prow[j] = sc[t];
+            dsrow[j] = ds;
+            s_ds[j] = ds;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < d; c += 64) {
+        float acc = 0.f;
+        const float* kc = k + (long)b * nk * ldk + h * d + c;
+        for (int j = 0; j < nk; ++j) acc += s_ds[j] * kc[(long)j * ldk];
+        dq[((long)b * nq + i) * lddq + h * d + c] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ dout,
+                                                            int ldo, int heads, int nq, int nk, int d,
+                                                            const float* __restrict__ pbuf, const float* __restrict__ dsbuf,
+                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                            long total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long colid = (long)blockIdx.x * 4 + wave;  // (b * heads + h) * nk + j
+    if (colid >= total) return;
+    const int j = (int)(colid % nk);
+    const int h = (int)((colid / nk) % heads);
+    const int b = (int)(colid / ((long)nk * heads));
+    const float* pcol = pbuf + ((long)(b * heads + h) * nq) * nk + j;
+    const float* dscol = dsbuf + ((long)(b * heads + h) * nq) * nk + j;
+    for (int c0 = 0; c0 < d; c0 += 64) {
+        const int c = c0 + lane;
+        float ak = 0.f, av = 0.f;
+        if (c < d) {
+            const float* qc = q + (long)b * nq * ldq + h * d + c;
+            const float* gc = dout + (long)b * nq * ldo + h * d + c;
+            for (int i = 0; i < nq; ++i) {
+                ak += dscol[(long)i * nk] * qc[(long)i * ldq];
+                av += pcol[(long)i * nk] * gc[(long)i * ldo];
+            }
+            dk[((long)b * nk + j) * lddk + h * d + c] = ak;
+            dv[((long)b * nk + j) * lddv + h * d + c] = av;
+        }
+    }
+}
+
 __global__ void geglu_fwd_kernel(const float* __restrict__ u, int ld, long rows, int inner, wd_bf16* __restrict__ out_hi,
                                  wd_bf16* __restrict__ out_lo, int out_ld) {
     const int i4 = inner >> 2;
@@ -737,5 +852,31 @@ extern "C" int wd_permute_dw(const float* packed, int ld, int n, int c, int ntap
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(permute_dw_kernel, dim3(grid_for((long)n * c * ntaps)), dim3(256), 0, st, packed, ld, n, c, ntaps, out);
+    return wd_check_launch();
+}
+
+extern "C" int64_t wd_attention_bwd_scratch_floats(int batch, int heads, int nq, int nk) {
+    return (int64_t)2 * batch * heads * nq * nk;
+}
+
+extern "C" int wd_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout,
+                                int ldo, int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq,
+                                float* dk, int lddk, float* dv, int lddv, float* scratch, int64_t scratch_floats,
+                                void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !scratch) return WD_EINVAL;
+    if (batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0 || nk > 64 * AG_NJ || d <= 0 || d % 4) return WD_EINVAL;
+    if (ldk % 4 || ldv % 4) return WD_EINVAL;
+    if (scratch_floats < wd_attention_bwd_scratch_floats(batch, heads, nq, nk)) return WD_EINVAL;
+    const size_t smem = (size_t)4 * (2 * d + nk) * sizeof(float);
+    if (smem > 64 * 1024) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* pbuf = scratch;
+    float* dsbuf = scratch + (int64_t)batch * heads * nq * nk;
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    const long rows = (long)batch * heads * nq, cols = (long)batch * heads * nk;
+    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), smem, st, q, ldq, k, ldk, v, ldv, dout,
+                       ldo, heads, nq, nk, d, scale, dq, lddq, pbuf, dsbuf, rows);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, q, ldq, dout, ldo, heads, nq, nk,
+                       d, pbuf, dsbuf, dk, lddk, dv, lddv, cols);
     return wd_check_launch();
 }

@@ -198,9 +198,7 @@ class UNetBase(nn.Module):
             # ``predicted_noise = model(...)`` inside the training loop (train.py:287): the result carries a grad_fn whose
             # backward runs the HIP backward list and fills ``param.grad`` (reference layouts), so ``loss.backward()``,
             # ``optimizer.step()`` and ``ema.step_ema`` of the reference loop work unchanged.
-            if phosc is not None:
-                raise NotImplementedError("PHOSC-conditioned training step (next row, DESIGN.md)")
-            return _HipUNetStep.apply(self, x, timesteps, context, y, self._grad_anchor(x.device)).type(x.dtype)
+            return _HipUNetStep.apply(self, x, timesteps, context, y, phosc, self._grad_anchor(x.device)).type(x.dtype)
         out = self.engine.forward(x.float(), timesteps, context, y, phosc)
         return out.type(x.dtype)
 
@@ -219,12 +217,12 @@ class _HipUNetStep(torch.autograd.Function):
     asks for one)."""
 
     @staticmethod
-    def forward(ctx, model, x, timesteps, context, y, anchor):
+    def forward(ctx, model, x, timesteps, context, y, phosc, anchor):
         eng = model.train_engine
         ctx.eng = eng
-        return eng.forward_train(x.float(), timesteps, context, y).clone()
+        return eng.forward_train(x.float(), timesteps, context, y, phosc).clone()
 
     @staticmethod
     def backward(ctx, gout):
         ctx.eng.backward(gout.contiguous().float())
-        return None, None, None, None, None, torch.zeros_like(ctx.eng.model._anchor)
+        return None, None, None, None, None, None, torch.zeros_like(ctx.eng.model._anchor)

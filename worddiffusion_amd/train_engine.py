@@ -54,9 +54,6 @@ def _rup(x: int, m: int) -> int:
 
 class TrainEngine(UNetEngine):
     def __init__(self, model, variant: str):
-        if variant != "base":
-            raise NotImplementedError("the HIP training step covers unet.UNetModel (train.py:403); the PHOSC variant's "
-                                      "spatial self-attention backward is the next row (DESIGN.md)")
         super().__init__(model, variant)
         self._tplans: Dict[tuple, TrainPlan] = {}
         self._grad: Dict[int, torch.Tensor] = {}     # id(param) -> gradient buffer (possibly a view into a group)
@@ -91,7 +88,12 @@ class TrainEngine(UNetEngine):
                 for d, tb in enumerate(mod.transformer_blocks):
                     p = f"{name}.tb{d}"
                     for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
-                        R.matrix(f"B:{p}.{tag}.q.w", inner, inner).bwd(at.to_q.weight)
+                        if tag == "a1" and self.variant == "phosc":  # spatial self-attention: fused q|k|v projection
+                            R.matrix(f"B:{p}.a1.qkv.w", inner, 3 * inner)
+                            for i, l in enumerate((at.to_q, at.to_k, at.to_v)):
+                                R[f"B:{p}.a1.qkv.w"].bwd(l.weight, col_off=i * inner)
+                        else:
+                            R.matrix(f"B:{p}.{tag}.q.w", inner, inner).bwd(at.to_q.weight)
                         R.matrix(f"B:{p}.{tag}.o.w", inner, inner).bwd(at.to_out[0].weight)
                     ffi = tb.ff.net[2].in_features
                     # the training forward keeps the GEGLU pre-activation: plain [x | gate] row order (unet.py:128)
@@ -337,9 +339,17 @@ class TrainEngine(UNetEngine):
         lib = self.lib
         B = self._B
         inner = heads * d
+        if nk > 16:
+            # long key sets (spatial self-attention, PHOSC context): dK | dV land in the destination rows directly
+            need = lib.wd_attention_bwd_scratch_floats(B, heads, nq, nk)
+            scr = self._scratch("attn_bwd", max(need, self._max_attn_scr), torch.float32)
+            ops.append((lib.wd_attention_bwd, (q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO.data_ptr(), dO.shape[1], B, heads, nq, nk, d,
+                                               float(scale), dq_ptr, lddq, dkv_ptr, dkv_pitch_floats, dkv_ptr + 4 * inner,
+                                               dkv_pitch_floats, scr.data_ptr(), scr.numel()), what))
+            return
         nwg = lib.wd_attention_bwd_small_nwg(heads, nq, nk, d)
-        if nwg <= 0 or nk > 16:
-            raise NotImplementedError(f"attention backward for {nk} keys (<= 16 context tokens supported)")
+        if nwg <= 0:
+            raise NotImplementedError(f"attention backward shape heads={heads} nq={nq} nk={nk} d={d}")
         part = self._f32(P, B, nwg, nk, 2, inner)
         ops.append((lib.wd_attention_bwd_small, (q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO.data_ptr(), dO.shape[1], B, heads, nq, nk,
                                                  d, float(scale), dq_ptr, lddq, part.data_ptr(), None), what))
@@ -504,19 +514,30 @@ class TrainEngine(UNetEngine):
         for di, tb in enumerate(mod.transformer_blocks):
             p = f"{name}.tb{di}"
             rec = dict(tb=tb, p=p, tok=cur)
-            # both attentions read norm2 in the base model (unet.py:337-345)
+            # base model: both attentions are cross-attentions reading norm2 (unet.py:337-345); PHOSC model: attn1 is the
+            # spatial self-attention behind norm1 (unetPhosc.py:241-246)
             for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
-                n_pl = self._ln(P, ops, f"{p}.norm2({tag})", cur, M, inner, p + ".norm2")
-                q = self._f32(P, M, inner)
-                self._gemm(ops, f"{p}.{tag}.q", [self._src(n_pl, inner)], f"{p}.{tag}.q.w", M, hw, out_f32=q, out_ld=inner)
-                ko = self.kv_off[f"{p}.{tag}"]
+                self_attn = tag == "a1" and self.variant == "phosc"
+                ln = "norm1" if self_attn else "norm2"
+                n_pl = self._ln(P, ops, f"{p}.{ln}({tag})", cur, M, inner, f"{p}.{ln}")
                 o = self._planes(P, M, inner)
-                self._attention(ops, f"{p}.{tag}", q.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
-                                self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o)
+                if self_attn:
+                    qkv = self._f32(P, M, 3 * inner)
+                    self._gemm(ops, p + ".a1.qkv", [self._src(n_pl, inner)], p + ".a1.qkv.w", M, hw, out_f32=qkv,
+                               out_ld=3 * inner)
+                    self._attention(ops, p + ".a1", qkv.data_ptr(), 3 * inner, qkv.data_ptr() + 4 * inner, 3 * inner,
+                                    qkv.data_ptr() + 8 * inner, 3 * inner, heads, hw, hw, d, scale, o)
+                    rec[tag] = dict(at=at, x=cur, n=n_pl, qkv=qkv, o=o, self_attn=True, ln=ln)
+                else:
+                    q = self._f32(P, M, inner)
+                    self._gemm(ops, f"{p}.{tag}.q", [self._src(n_pl, inner)], f"{p}.{tag}.q.w", M, hw, out_f32=q, out_ld=inner)
+                    ko = self.kv_off[f"{p}.{tag}"]
+                    self._attention(ops, f"{p}.{tag}", q.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                                    self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o)
+                    rec[tag] = dict(at=at, x=cur, n=n_pl, q=q, o=o, ko=ko, self_attn=False, ln=ln)
                 nxt = self._f32(P, M, inner)
                 self._gemm(ops, f"{p}.{tag}.out", [self._src(o, inner)], f"{p}.{tag}.o.w", M, hw,
                            bias=self._w[f"{p}.{tag}.o.b"], resid=cur.data_ptr(), resid_ld=inner, out_f32=nxt, out_ld=inner)
-                rec[tag] = dict(at=at, x=cur, n=n_pl, q=q, o=o, ko=ko)
                 cur = nxt
             ffi = tb.ff.net[2].in_features
             n3 = self._ln(P, ops, p + ".norm3", cur, M, inner, p + ".norm3")
@@ -579,17 +600,29 @@ class TrainEngine(UNetEngine):
                                      [dict(planes=r["o"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.{tag}.o.w",
                                            wgrad=self._pgrad(at.to_out[0].weight), dx=[(do, inner, 0, 0, inner)], dx_rows=M,
                                            dx_hw=hw)], bias=[self._pgrad(at.to_out[0].bias)])
-                    dq = self._f32(P, M, inner)
-                    ko = r["ko"]
-                    self._attn_bwd(P, f"{p}.{tag}:bwd", r["q"].data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
-                                   self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, do, heads, hw, L, d, scale,
-                                   dq.data_ptr(), inner, self._dkv.data_ptr() + 4 * ko, self.kv_total)
                     dn = self._f32(P, M, inner)
-                    self._bwd_linear(P, f"{p}.{tag}.q", dq, M, inner, hw,
-                                     [dict(planes=r["n"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.{tag}.q.w",
-                                           wgrad=self._pgrad(at.to_q.weight), dx=[(dn, inner, 0, 0, inner)], dx_rows=M,
-                                           dx_hw=hw)])
-                    self._ln_bwd(P, f"{p}.norm2({tag}):bwd", r["x"], M, inner, tb.norm2, p + ".norm2", dn, dcur, 1)
+                    if r["self_attn"]:
+                        qkv = r["qkv"]
+                        dqkv = self._f32(P, M, 3 * inner)
+                        self._attn_bwd(P, f"{p}.a1:bwd", qkv.data_ptr(), 3 * inner, qkv.data_ptr() + 4 * inner, 3 * inner,
+                                       qkv.data_ptr() + 8 * inner, 3 * inner, do, heads, hw, hw, d, scale, dqkv.data_ptr(),
+                                       3 * inner, dqkv.data_ptr() + 4 * inner, 3 * inner)
+                        self._bwd_linear(P, p + ".a1.qkv", dqkv, M, 3 * inner, hw,
+                                         [dict(planes=r["n"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.a1.qkv.w",
+                                               wgrad=self._pgroup([at.to_q.weight, at.to_k.weight, at.to_v.weight]),
+                                               dx=[(dn, inner, 0, 0, inner)], dx_rows=M, dx_hw=hw)])
+                    else:
+                        dq = self._f32(P, M, inner)
+                        ko = r["ko"]
+                        self._attn_bwd(P, f"{p}.{tag}:bwd", r["q"].data_ptr(), inner, self._kv.data_ptr() + 4 * ko,
+                                       self.kv_total, self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, do, heads, hw, L, d,
+                                       scale, dq.data_ptr(), inner, self._dkv.data_ptr() + 4 * ko, self.kv_total)
+                        self._bwd_linear(P, f"{p}.{tag}.q", dq, M, inner, hw,
+                                         [dict(planes=r["n"], c=inner, ntaps=1, hw_src=hw, wb=f"B:{p}.{tag}.q.w",
+                                               wgrad=self._pgrad(at.to_q.weight), dx=[(dn, inner, 0, 0, inner)], dx_rows=M,
+                                               dx_hw=hw)])
+                    self._ln_bwd(P, f"{p}.{r['ln']}({tag}):bwd", r["x"], M, inner, getattr(tb, r["ln"]), f"{p}.{r['ln']}", dn,
+                                 dcur, 1)
             dg = self._f32(P, M, c)
             self._bwd_linear(P, name + ".proj_in", dcur, M, inner, hw,
                              [dict(planes=gpl, c=c, ntaps=1, hw_src=hw, wb="B:" + name + ".pi.w",
@@ -601,17 +634,29 @@ class TrainEngine(UNetEngine):
         return out
 
     # ------------------------------------------------------------------------------------------ plan
-    def _size_scratch(self, B, H, W, L):
+    def _size_scratch(self, B, H, W, L, ctx_len=0, phosc_len=0):
         m = self.model
         mc = m.model_channels
         cmax = mc * max(m.channel_mult)
-        M = B * H * W
+        M = max(B * H * W, B * L)
         mpad = _rup(M, 64)
         nmax = max(8 * cmax, self.film_total, self.kv_total, 4 * mc)        # widest d(output): GEGLU pre-activation
         kmax = max(9 * 2 * cmax, 4 * cmax, 4 * mc, self.kpad_in)           # longest (tap, channel) list: 3x3 over a concat
         self._max_dpl = M * nmax
         self._max_doutT = nmax * mpad
         self._max_xT = kmax * mpad
+        heads_max = max([mod.heads for _, mod in self._walk() if isinstance(mod, SpatialTransformerParams)] or [1])
+        scr = 0
+        if self.variant == "phosc" and H * W > 16:
+            scr = max(scr, 2 * B * heads_max * (H * W) ** 2)
+        if L > 16:
+            scr = max(scr, 2 * B * heads_max * H * W * L)
+        for n_tok in (ctx_len, phosc_len):
+            if n_tok > 16:
+                scr = max(scr, 2 * B * n_tok * n_tok)
+        self._max_attn_scr = scr
+        if scr:
+            self._scratch("attn_bwd", scr, torch.float32)
         self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)
         self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)
         self._scratch("xT", 2 * self._max_xT, torch.bfloat16)
@@ -619,8 +664,8 @@ class TrainEngine(UNetEngine):
         if self._ws is None or self._ws.numel() < 8 * 2 * cmax * 9 * cmax:
             self._ws = torch.empty(max(128 * 128 * 160 * 8, 8 * 2 * cmax * 9 * cmax), dtype=torch.float32, device=self.device)
 
-    def plan_train(self, B: int, H: int, W: int, ctx_len: int) -> TrainPlan:
-        key = (B, H, W, ctx_len, self.npass)
+    def plan_train(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int = 0) -> TrainPlan:
+        key = (B, H, W, ctx_len, phosc_len, self.npass)
         if key in self._tplans:
             return self._tplans[key]
         if self._tplans:
@@ -631,10 +676,12 @@ class TrainEngine(UNetEngine):
         lib = self.lib
         if ctx_len == 0:
             raise NotImplementedError("context=None: every reference script conditions on the word (unet.py:1605)")
+        if phosc_len and self.variant != "phosc":
+            raise ValueError("phoscLabels are an input of UNetModelPhosc only")
         P = TrainPlan()
         self._cur_plan = P
         self._B = B
-        L = ctx_len
+        L = ctx_len + phosc_len
         self._ctx_len = L
         self._tape = []
         self._pw = set()
@@ -644,28 +691,37 @@ class TrainEngine(UNetEngine):
         ted = 4 * mc
         cd = m.context_dim
         lo_ok = self.npass == 3
-        self._size_scratch(B, H, W, L)
+        self._size_scratch(B, H, W, L, ctx_len, phosc_len)
         step = P.step
 
         P.x_in = torch.zeros((B, m.in_channels, H, W), dtype=torch.float32, device=dev)
         P.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
         P.y_in = torch.zeros((B,), dtype=torch.int64, device=dev)
-        P.ctx_in = torch.zeros((B, L), dtype=torch.int64, device=dev)
+        P.ctx_in = torch.zeros((B, ctx_len), dtype=torch.int64, device=dev)
+        P.phosc_in = torch.zeros((B, max(phosc_len, 1)), dtype=torch.int32, device=dev)
 
         # ---- conditioning path (differentiated, so it is part of every step): CharacterEncoder + all K/V projections
         we = m.word_emb
-        if L > m.max_seq_len:
-            raise ValueError(f"context length {L} exceeds max_seq_len {m.max_seq_len} (the reference fails too)")
-        e = self._planes(P, B * L, cd)
-        step.append((lib.wd_embed_tokens, (P.ctx_in.data_ptr(), 1, B * L, L, self._w["we.table"].data_ptr(),
-                                           self._w["we.table"].shape[0], cd, self._w["pe"].data_ptr(), e[0].data_ptr(),
-                                           e[1].data_ptr() if lo_ok else None, cd), "word_emb.embedding"))
-        qkv = self._f32(P, B * L, 3 * cd)
-        self._gemm(step, "word_emb.qkv", [self._src(e, cd)], "we.qkv.w", B * L, L, bias=self._w["we.qkv.b"], out_f32=qkv,
-                   out_ld=3 * cd)
+        msl = m.max_seq_len
         ctx_pl = self._planes(P, B * L, cd)
-        self._attention(step, "word_emb.attention", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
-                        qkv.data_ptr() + 8 * cd, 3 * cd, 1, L, L, cd, 1.0, ctx_pl, out_rows=L, out_row0=0)
+        groups = []
+        for (ids, n_tok, row0, i64) in ((P.ctx_in, ctx_len, 0, 1), (P.phosc_in, phosc_len, ctx_len, 0)):
+            if n_tok == 0:
+                continue
+            use_pe = (self.variant == "base") or (n_tok <= msl)  # unetPhosc.py:726-729 skips the table for PHOSC vectors
+            if use_pe and n_tok > msl:
+                raise ValueError(f"context length {n_tok} exceeds max_seq_len {msl} (the reference fails too)")
+            e = self._planes(P, B * n_tok, cd)
+            step.append((lib.wd_embed_tokens, (ids.data_ptr(), i64, B * n_tok, n_tok, self._w["we.table"].data_ptr(),
+                                               self._w["we.table"].shape[0], cd, self._w["pe"].data_ptr() if use_pe else None,
+                                               e[0].data_ptr(), e[1].data_ptr() if lo_ok else None, cd), "word_emb.embedding"))
+            qkv = self._f32(P, B * n_tok, 3 * cd)
+            self._gemm(step, "word_emb.qkv", [self._src(e, cd)], "we.qkv.w", B * n_tok, n_tok, bias=self._w["we.qkv.b"],
+                       out_f32=qkv, out_ld=3 * cd)
+            # Word_Attention: softmax(q k^T) v without 1/sqrt(d) (unet.py:831-835)
+            self._attention(step, "word_emb.attention", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
+                            qkv.data_ptr() + 8 * cd, 3 * cd, 1, n_tok, n_tok, cd, 1.0, ctx_pl, out_rows=L, out_row0=row0)
+            groups.append((ids, n_tok, row0, i64, e, qkv))
         self._kv = self._f32(P, B * L, self.kv_total)
         self._dkv = self._f32(P, B * L, self.kv_total)
         self._gemm(step, "cross.kv", [self._src(ctx_pl, cd)], "kv.w", B * L, L, out_f32=self._kv, out_ld=self.kv_total)
@@ -793,35 +849,44 @@ class TrainEngine(UNetEngine):
         self._bwd_linear(P, "cross.kv", self._dkv, B * L, self.kv_total, L,
                          [dict(planes=ctx_pl, c=cd, ntaps=1, hw_src=L, wb="B:kv.w", wgrad=kv_w, dx=[(dctx, cd, 0, 0, cd)],
                                dx_rows=B * L, dx_hw=L)])
-        dqkv = self._f32(P, B * L, 3 * cd)
-        self._attn_bwd(P, "word_emb.attention:bwd", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
-                       qkv.data_ptr() + 8 * cd, 3 * cd, dctx, 1, L, L, cd, 1.0, dqkv.data_ptr(), 3 * cd,
-                       dqkv.data_ptr() + 4 * cd, 3 * cd)
         at = we.attention
         qkv_w = self._pgroup([at.linear_query.weight, at.linear_key.weight, at.linear_value.weight])
         qkv_b = self._pgroup([at.linear_query.bias, at.linear_key.bias, at.linear_value.bias])
-        de = self._f32(P, B * L, cd)
-        self._bwd_linear(P, "word_emb.qkv", dqkv, B * L, 3 * cd, L,
-                         [dict(planes=e, c=cd, ntaps=1, hw_src=L, wb="B:we.qkv.w", wgrad=qkv_w, dx=[(de, cd, 0, 0, cd)],
-                               dx_rows=B * L, dx_hw=L)], bias=[qkv_b])
         dtab = self._pgrad(we.embedding.weight)
-        bops.append((lib.wd_embedding_bwd, (P.ctx_in.data_ptr(), 1, B * L, de.data_ptr(), cd, we.embedding.weight.shape[0], cd,
-                                            dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
+        for (ids, n_tok, row0, i64, e, qkv) in groups:
+            if n_tok == L:
+                dgrp = dctx
+            else:  # this group's rows of every sample, made contiguous
+                dgrp = self._f32(P, B * n_tok, cd)
+                bops.append((lib.wd_copy2d, (dgrp.data_ptr(), 4 * n_tok * cd, dctx.data_ptr() + 4 * row0 * cd, 4 * L * cd,
+                                             4 * n_tok * cd, B), "d(context):group rows"))
+            dqkv = self._f32(P, B * n_tok, 3 * cd)
+            self._attn_bwd(P, "word_emb.attention:bwd", qkv.data_ptr(), 3 * cd, qkv.data_ptr() + 4 * cd, 3 * cd,
+                           qkv.data_ptr() + 8 * cd, 3 * cd, dgrp, 1, n_tok, n_tok, cd, 1.0, dqkv.data_ptr(), 3 * cd,
+                           dqkv.data_ptr() + 4 * cd, 3 * cd)
+            de = self._f32(P, B * n_tok, cd)
+            self._bwd_linear(P, "word_emb.qkv", dqkv, B * n_tok, 3 * cd, n_tok,
+                             [dict(planes=e, c=cd, ntaps=1, hw_src=n_tok, wb="B:we.qkv.w", wgrad=qkv_w,
+                                   dx=[(de, cd, 0, 0, cd)], dx_rows=B * n_tok, dx_hw=n_tok)], bias=[qkv_b])
+            bops.append((lib.wd_embedding_bwd, (ids.data_ptr(), i64, B * n_tok, de.data_ptr(), cd, we.embedding.weight.shape[0], cd,
+                                                dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
         self._tape = []
         self._tplans[key] = P
         return P
 
     # ------------------------------------------------------------------------------------------ run
-    def forward_train(self, x, t, context, y):
+    def forward_train(self, x, t, context, y, phosc=None):
         """Training forward: keeps every intermediate for ``backward``.  Returns the plan's output buffer (no copy)."""
         self.refresh_weights()
         B, _, H, W = x.shape
         if context is None:
             raise NotImplementedError("context=None")
-        P = self.plan_train(B, H, W, context.shape[1])
+        P = self.plan_train(B, H, W, context.shape[1], 0 if phosc is None else phosc.shape[1])
         P.x_in.copy_(x, non_blocking=True)
         P.t_in.copy_(t, non_blocking=True)
         P.ctx_in.copy_(context, non_blocking=True)
+        if phosc is not None:
+            P.phosc_in.copy_(phosc.to(torch.int32) if phosc.dtype != torch.int32 else phosc, non_blocking=True)
         if y is not None:
             P.y_in.copy_(y, non_blocking=True)
         stream = torch.cuda.current_stream(self.device).cuda_stream

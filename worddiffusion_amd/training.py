@@ -36,10 +36,10 @@ class TrainStep:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
 
-    def _prepare(self, B, H, W, L, dev):
+    def _prepare(self, B, H, W, L, dev, phosc_len=0):
         eng = self.eng
         eng.refresh_weights()
-        P = eng.plan_train(B, H, W, L)
+        P = eng.plan_train(B, H, W, L, phosc_len)
         ah = self.diffusion.alpha_hat.cpu()
         self._sa, self._sb = torch.sqrt(ah).to(dev).contiguous(), torch.sqrt(1 - ah).to(dev).contiguous()
         self._x0 = torch.zeros_like(P.x_in)
@@ -64,16 +64,18 @@ class TrainStep:
         P.run_bwd(st)
 
     def __call__(self, latents: torch.Tensor, text_features: torch.Tensor, labels: Optional[torch.Tensor],
-                 t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                 phoscLabels: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One optimisation step on a batch of latents [B, C, H, W]; returns the loss as a device tensor [1] (the
         reference's ``loss.item()`` per step, train.py:295, is the caller's choice)."""
         if not latents.is_cuda:
             raise N.NativeError("TrainStep runs on the GPU only (no CPU fallback)")
         dev = latents.device
         B, _, H, W = latents.shape
-        key = (B, H, W, text_features.shape[1], str(dev))
+        phosc_len = 0 if phoscLabels is None else phoscLabels.shape[1]
+        key = (B, H, W, text_features.shape[1], phosc_len, str(dev))
         if key != self._key:
-            self._prepare(B, H, W, text_features.shape[1], dev)
+            self._prepare(B, H, W, text_features.shape[1], dev, phosc_len)
             self._key = key
         lib, P = self.lib, self._P
         if t is None:
@@ -86,6 +88,9 @@ class TrainStep:
             st = self._stream.cuda_stream
             P.t_in.copy_(t, non_blocking=True)
             P.ctx_in.copy_(text_features, non_blocking=True)
+            if phoscLabels is not None:  # UNetModelPhosc: PHOSC vector appended to the context (unetPhosc.py:1119-1131)
+                P.phosc_in.copy_(phoscLabels.to(torch.int32) if phoscLabels.dtype != torch.int32 else phoscLabels,
+                                 non_blocking=True)
             if labels is not None:
                 P.y_in.copy_(labels, non_blocking=True)
             self._x0.copy_(latents, non_blocking=True)
