@@ -450,7 +450,11 @@ __device__ __forceinline__ int lds_off2(int row, int ch) { return row * 128 + ((
 // KS = 2: 8 waves; waves 4..7 shadow waves 0..3 on the same output tile but multiply the second half of every
 //         64-deep stage (k-steps 2,3), so each SIMD hosts two independent MFMA / ds_read streams that cover each
 //         other's LDS latency; the two partial accumulators are summed once through LDS before the epilogue.
-template <int BM, int BN, int NPASS, int KS>
+// PP (KS = 2 only): "ping-pong" - the second K-half group runs its MFMAs one phase late (on the fragments it read in the
+//         previous stage), so that on every SIMD one wave is in its LDS-read phase while the other is in its MFMA phase:
+//         the LDS port (192 KB of fragment reads + 74 KB of DMA writes per stage) and the MFMA pipe work concurrently
+//         instead of alternately.
+template <int BM, int BN, int NPASS, int KS, bool PP = false>
 __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int NW = 4 * KS;
@@ -635,16 +639,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
 
     const int frow = lane & 31, fhalf = lane >> 5;
     constexpr int NGRP = KK_PER * TN;  // MFMA groups (one 32x32 tile x one 16-deep k-step) of this wave per stage
-    for (int kit = 0; kit < nk; ++kit) {
-        __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
-        const bool more = kit + 1 < nk;
-        if (more) {
-            prep(k_begin + kit + 1);
-            advance();
-        }
-        const char* base = smem + (kit & 1) * STAGE;
-        char* nbase = smem + ((kit + 1) & 1) * STAGE;
-        bf16x8 fa[KK_PER][NPL], fb[KK_PER][TN][NPL];
+    bf16x8 fa[KK_PER][NPL], fb[KK_PER][TN][NPL];
+    auto read_frags = [&](const char* base) {
 #pragma unroll
         for (int k2 = 0; k2 < KK_PER; ++k2) {
             const int ch = (kh * KK_PER + k2) * 2 + fhalf;
@@ -658,7 +654,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 for (int p = 0; p < NPL; ++p) fb[k2][t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_stage = [&](bool more, char* nbase) {
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             const int k2 = g / TN, t = g % TN;
@@ -673,6 +670,42 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 for (int sl = g * NSLOT / NGRP; sl < (g + 1) * NSLOT / NGRP; ++sl) fire(sl, nbase);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (PP && KS == 2 && kh == 1) {
+        // late group (its own loop, so that the fragments carried across the barrier do not constrain the early group's
+        // register allocation): multiply the fragments of the previous stage while the early group reads this one; only
+        // then (fragments dead) compute and issue its share of the next stage's DMA, then read this stage
+        for (int kit = 0; kit < nk; ++kit) {
+            __syncthreads();
+            const bool more = kit + 1 < nk;
+            const char* base = smem + (kit & 1) * STAGE;
+            char* nbase = smem + ((kit + 1) & 1) * STAGE;
+            if (kit > 0) mfma_stage(false, nbase);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                prep(k_begin + kit + 1);
+                advance();
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) fire(sl, nbase);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(base);
+        }
+        if (nk > 0) mfma_stage(false, smem);
+    } else {
+        for (int kit = 0; kit < nk; ++kit) {
+            __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+            const bool more = kit + 1 < nk;
+            const char* base = smem + (kit & 1) * STAGE;
+            char* nbase = smem + ((kit + 1) & 1) * STAGE;
+            if (more) {
+                prep(k_begin + kit + 1);
+                advance();
+            }
+            read_frags(base);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_stage(more, nbase);
         }
     }
 
@@ -1050,7 +1083,7 @@ int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
-template <int BM, int BN, int NPASS, int KS>
+template <int BM, int BN, int NPASS, int KS, bool PP = false>
 int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int loop_smem = 2 * NPL * (BM + BN) * 128 + 9 * BM * 4;
@@ -1058,14 +1091,14 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS, KS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS, KS, PP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return WD_ELAUNCH;
         attr_done = true;
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
     WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
+    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS, PP>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
                        nbn, nbm);
     if (a.ksplit > 1) {
         // the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups
@@ -1164,7 +1197,9 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
     static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
     const int ks = ks_env == 1 ? 1 : 2;
+    static const bool pp = getenv("WDIFF_GEMM_PP") ? atoi(getenv("WDIFF_GEMM_PP")) != 0 : true;
 #define WD_DISPATCH(BM_, BN_)                                                                      \
+    if (v2ok && ks == 2 && pp) return a.npass == 3 ? launch2<BM_, BN_, 3, 2, true>(a, st) : launch2<BM_, BN_, 1, 2, true>(a, st); \
     if (v2ok && ks == 2) return a.npass == 3 ? launch2<BM_, BN_, 3, 2>(a, st) : launch2<BM_, BN_, 1, 2>(a, st); \
     if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3, 1>(a, st) : launch2<BM_, BN_, 1, 1>(a, st); \
     a.ksplit = 1;                                                                                   \
