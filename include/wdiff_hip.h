@@ -134,6 +134,22 @@ int wd_attention(const float* q, int ldq, const float* k, int ldk, const float* 
 int wd_timestep_embedding(const int64_t* t, int batch, const float* freqs, int half,
                           wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
 
+/* Cross-attention over <= 10 context tokens, folded and fused (CrossAttention of unet.py:164-279 as used by
+ * BasicTransformerBlock unet.py:337-345: x + to_out(softmax(to_q(LN(x)) K^T * scale) V)).
+ * wd_xattn_fold (once per context): Mq[b][h*L+j][n] = scale * sum_c K[b*L+j][h*d+c] * Wq[h*d+c][n],
+ *                                   Mo[b][h*L+j][n] = sum_c V[b*L+j][h*d+c] * Wo[n][h*d+c]   (fp32; wq [heads*d][c], wo [c][heads*d]).
+ * wd_xattn_fused (per step): out = x + bias + softmax_heads(LN(x; gamma, beta, eps) . Mq[b]^T) . Mo[b]; when n_hi != NULL also
+ * the following LayerNorm (gamma2, beta2, eps2) of `out` as split-bf16 planes.  Shapes: wd_xattn_supported(c, heads, L).
+ * mq_pl [batch][2][64][c] / mot_pl [batch][2][c][64] (zero-initialised by the caller, filled by wd_xattn_fold) are the same
+ * matrices as split-bf16 MFMA operands; when given, the two products of wd_xattn_fused run on MFMA (fp32 VALU otherwise). */
+int wd_xattn_supported(int c, int heads, int L);
+int wd_xattn_fold(const float* k, int ldk, const float* v, int ldv, int batch, int heads, int L, int d, float scale,
+                  const float* wq, const float* wo, int c, float* mq, float* mo, wd_bf16* mq_pl, wd_bf16* mot_pl, void* stream);
+int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, const float* gamma, const float* beta, float eps,
+                   const float* mq, const float* mo, int heads, int L, const float* bias, float* out, int out_ld,
+                   const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld,
+                   const wd_bf16* mq_pl, const wd_bf16* mot_pl, void* stream);
+
 /* nn.Embedding lookup + positional encoding (CharacterEncoder, unet.py:860-872; PE skipped when pe == NULL,
  * unetPhosc.py:726-729): planes[r][:] = table[ids[r]][:] + pe[r % seq_len][:]. ids are int64 or int32. */
 int wd_embed_tokens(const void* ids, int ids_are_i64, int rows, int seq_len, const float* table, int vocab, int c,

@@ -468,3 +468,54 @@ def test_noise_images_and_ema_exact():
     N.check(lib.wd_ema_update(ed.data_ptr(), pd.data_ptr(), ema.numel(), 0.995, _st()), "ema")
     torch.cuda.synchronize()
     assert float((ed.cpu() - ref).abs().max()) <= 1e-9 + 2 ** -24 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,hw,c,heads,L", [(3, 256, 320, 4, 10), (2, 70, 320, 4, 10), (2, 32, 64, 4, 7), (2, 64, 64, 2, 10)])
+def test_folded_cross_attention(B, hw, c, heads, L):
+    """wd_xattn_fold + wd_xattn_fused == x + to_out(attention(to_q(LN(x)), K, V)) (unet.py:164-279,337-345) and the LayerNorm
+    that follows, against fp64 torch."""
+    lib = N.lib()
+    assert lib.wd_xattn_supported(c, heads, L) == 1
+    g = torch.Generator().manual_seed(hw + c + L)
+    d = c // heads
+    x = torch.randn(B * hw, c, generator=g) * 1.5 + 0.3
+    kv = torch.randn(B * L, 2 * c + 8, generator=g) * 0.5
+    wq = torch.randn(c, c, generator=g) / c ** 0.5
+    wo = torch.randn(c, c, generator=g) / c ** 0.5
+    bo = torch.randn(c, generator=g) * 0.1
+    ga, be, ga2, be2 = (torch.randn(c, generator=g) * 0.2 + (1.0 if i % 2 == 0 else 0.0) for i in range(4))
+    scale = d ** -0.5
+    xd = x.double()
+    n1 = F.layer_norm(xd, (c,), ga.double(), be.double(), 1e-5)
+    q = n1 @ wq.double().t()
+    k, v = kv[:, :c].double(), kv[:, c:2 * c].double()
+
+    def hd(t, n):
+        return t.reshape(B, n, heads, d).permute(0, 2, 1, 3)
+
+    att = torch.softmax(hd(q, hw) @ hd(k, L).transpose(-1, -2) * scale, -1)
+    o = (att @ hd(v, L)).permute(0, 2, 1, 3).reshape(B * hw, c)
+    ref = o @ wo.double().t() + bo.double() + xd
+    ref_n = F.layer_norm(ref, (c,), ga2.double(), be2.double(), 1e-5)
+    dev = lambda t: t.contiguous().to(DEV)  # noqa: E731
+    xg, kvg, wqg, wog, bog, gag, beg, ga2g, be2g = map(dev, (x, kv, wq, wo, bo, ga, be, ga2, be2))
+    mq = torch.zeros(B, heads * L, c, device=DEV)
+    mo = torch.zeros(B, heads * L, c, device=DEV)
+    mq_pl = torch.zeros(B, 2, 64, c, dtype=torch.bfloat16, device=DEV)
+    mot_pl = torch.zeros(B, 2, c, 64, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.wd_xattn_fold(kvg.data_ptr(), kv.shape[1], kvg.data_ptr() + 4 * c, kv.shape[1], B, heads, L, d, scale,
+                              wqg.data_ptr(), wog.data_ptr(), c, mq.data_ptr(), mo.data_ptr(), mq_pl.data_ptr(), mot_pl.data_ptr(),
+                              _st()), "fold")
+    for planes in ((None, None), (mq_pl.data_ptr(), mot_pl.data_ptr())):  # fp32 VALU form, MFMA form
+        out = torch.zeros(B * hw, c, device=DEV)
+        pl = torch.zeros(2, B * hw, c, dtype=torch.bfloat16, device=DEV)
+        N.check(lib.wd_xattn_fused(xg.data_ptr(), c, B, hw, c, gag.data_ptr(), beg.data_ptr(), 1e-5, mq.data_ptr(), mo.data_ptr(),
+                                   heads, L, bog.data_ptr(), out.data_ptr(), c, ga2g.data_ptr(), be2g.data_ptr(), 1e-5,
+                                   pl[0].data_ptr(), pl[1].data_ptr(), c, planes[0], planes[1], _st()), "fused")
+        out2 = torch.zeros(B * hw, c, device=DEV)
+        N.check(lib.wd_xattn_fused(xg.data_ptr(), c, B, hw, c, gag.data_ptr(), beg.data_ptr(), 1e-5, mq.data_ptr(), mo.data_ptr(),
+                                   heads, L, bog.data_ptr(), out2.data_ptr(), c, None, None, 0.0, None, None, 0, planes[0],
+                                   planes[1], _st()), "fused (no LN)")
+        torch.cuda.synchronize()
+        assert max_rel(out.cpu(), ref) < 2e-5 and torch.equal(out, out2)
+        assert max_rel(unplanes(pl).cpu(), ref_n) < 3e-5

@@ -70,6 +70,9 @@ _SIGS = {
     "wd_repack_multi": (_i, [_vp, _i, C.c_int64, _vp]),
     "wd_attention_bwd_scratch_floats": (C.c_int64, [_i, _i, _i, _i]),
     "wd_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, C.c_int64, _vp]),
+    "wd_xattn_supported": (_i, [_i, _i, _i]),
+    "wd_xattn_fold": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "wd_xattn_fused": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "wd_add": (_i, [_vp, _vp, C.c_int64, _vp]),
     "wd_permute_dw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wd_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, C.c_int64, _vp]),

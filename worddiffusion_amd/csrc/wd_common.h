@@ -59,13 +59,31 @@ __device__ __forceinline__ void wd_split4(const float4 v, uint2& hi, uint2& lo) 
 __device__ __forceinline__ float wd_silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float wd_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// 64-lane reductions on the DPP path (quad permutes + row rotates inside each row of 16 lanes, then one v_readlane per
+// row): ~10 VALU-rate instructions instead of six dependent ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float wd_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wd_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += wd_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += wd_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += wd_dpp<0x124>(v);  // row_ror:4
+    v += wd_dpp<0x128>(v);  // row_ror:8  -> every lane holds the sum of its row of 16
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wd_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, wd_dpp<0xB1>(v));
+    v = fmaxf(v, wd_dpp<0x4E>(v));
+    v = fmaxf(v, wd_dpp<0x124>(v));
+    v = fmaxf(v, wd_dpp<0x128>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }

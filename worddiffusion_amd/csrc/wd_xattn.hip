@@ -1,0 +1,564 @@
+// Cross-attention over a handful of context tokens, folded and fused (base UNet: both attentions of every transformer
+// block attend to the <= 10 character tokens, unet.py:164-279,337-345; PHOSC UNet: attn2 without a PHOSC vector).
+//
+// K and V depend only on the context, so for every sample b and head h the projections around the attention fold into two
+// small per-sample matrices, computed once per sampling call (wd_xattn_fold):
+//     scores[t][h, j] = LN(x_t) . Mq[b][h, j][:],     Mq[b][h, j][n] = scale * sum_c K[b, j][h, c] * Wq[h*d + c][n]
+//     out[t][n]       = sum_{h, j} softmax_j(scores)[h, j] * Mo[b][h, j][n] + bias[n] + x_t[n],
+//                                                     Mo[b][h, j][n] = sum_c V[b, j][h, c] * Wo[n][h*d + c]
+// which is 8x fewer multiply-adds than  LN -> to_q GEMM -> attention -> to_out GEMM  and one launch instead of four.
+// Everything is fp32 (VALU): LayerNorm, 2 x (64 tokens x 320 x 40) products per workgroup out of LDS, softmax, residual.
+#include "wd_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int XHJ = 64;  // (head, key) pairs padded to two 32-wide MFMA tiles
+
+__global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v,
+                                                         int ldv, int heads, int L, int d, float scale,
+                                                         const float* __restrict__ wq, const float* __restrict__ wo, int c,
+                                                         float* __restrict__ mq, float* __restrict__ mo,
+                                                         wd_bf16* __restrict__ mq_pl, wd_bf16* __restrict__ mot_pl) {
+    // grid (L, heads, batch); one (b, h, j) row of both matrices per workgroup
+    extern __shared__ float s_kv[];  // [2][d]
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int inner = heads * d;
+    const float* kr = k + ((long)b * L + j) * ldk + h * d;
+    const float* vr = v + ((long)b * L + j) * ldv + h * d;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        s_kv[i] = kr[i];
+        s_kv[d + i] = vr[i];
+    }
+    __syncthreads();
+    const long orow = ((long)b * heads + h) * L + j;
+    for (int n = threadIdx.x; n < c; n += 256) {
+        float aq = 0.f, ao = 0.f;
+        const float* wqc = wq + (long)h * d * c + n;       // Wq[h*d + cc][n], coalesced over n
+        const float* woc = wo + (long)n * inner + h * d;   // Wo[n][h*d + cc]
+        for (int cc = 0; cc < d; ++cc) {
+            aq += s_kv[cc] * wqc[(long)cc * c];
+            ao += s_kv[d + cc] * woc[cc];
+        }
+        mq[orow * c + n] = aq * scale;
+        mo[orow * c + n] = ao;
+        if (mq_pl) {
+            // operands of the MFMA kernel: Mq as [b][plane][64 rows hj][c], Mo transposed as [b][plane][c][64 columns hj]
+            const int hj = h * L + j;
+            uint32_t hi, lo;
+            wd_split1(aq * scale, hi, lo);
+            mq_pl[(((long)b * 2 + 0) * XHJ + hj) * c + n] = (wd_bf16)hi;
+            mq_pl[(((long)b * 2 + 1) * XHJ + hj) * c + n] = (wd_bf16)lo;
+            wd_split1(ao, hi, lo);
+            mot_pl[(((long)b * 2 + 0) * c + n) * XHJ + hj] = (wd_bf16)hi;
+            mot_pl[(((long)b * 2 + 1) * c + n) * XHJ + hj] = (wd_bf16)lo;
+        }
+    }
+}
+
+constexpr int XT = 64;  // tokens per workgroup: 32 token pairs x 8 column groups
+
+template <int NI, int NH>  // NI = c / 32 (float4 columns per thread in the output phase), NH = ceil(heads * L / 8)
+__global__ void __launch_bounds__(256) xattn_fused_kernel(const float* __restrict__ x, int ld, int hw,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, const float* __restrict__ mq, const float* __restrict__ mo,
+                                                          int heads, int L, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int out_ld, const float* __restrict__ gamma2,
+                                                          const float* __restrict__ beta2, float eps2,
+                                                          wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo, int n_ld, int dbg) {
+    constexpr int C = NI * 32, C4 = C / 4, CP = C + 4, HJP = NH * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_x = reinterpret_cast<float*>(smem);  // [XT][CP] normalised tokens
+    float* s_m = s_x + XT * CP;                   // [HJP][CP] Mq, later Mo (rows >= heads*L are zero)
+    float* s_p = s_m + HJP * CP;                  // [XT][HJP + 1] scores / probabilities
+    const int b = blockIdx.y, t0 = blockIdx.x * XT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HJ = heads * L;
+    const long row0 = (long)b * hw + t0;
+    const int ntok = min(XT, hw - t0);
+
+    // ---- LayerNorm of the 64 tokens (one wave per token, two-pass in registers) -> s_x
+    constexpr int F = (C4 + 63) / 64;
+    for (int t = wave; t < ((dbg & 1) ? 4 : XT); t += 4) {
+        float4 v[F];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < C4 && t < ntok) v[i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + f * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wd_wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            if (f < C4) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            if (f < C4) {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
+                const float4 be = *reinterpret_cast<const float4*>(beta + f * 4);
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * ga.x + be.x; o.y = (v[i].y - mean) * rstd * ga.y + be.y;
+                o.z = (v[i].z - mean) * rstd * ga.z + be.z; o.w = (v[i].w - mean) * rstd * ga.w + be.w;
+                *reinterpret_cast<float4*>(s_x + t * CP + f * 4) = o;
+            }
+        }
+    }
+    const float* mqb = mq + (long)b * HJ * C;
+    const float* mob = mo + (long)b * HJ * C;
+    for (int e = tid; e < HJP * C4; e += 256) {
+        const int r = e / C4, f = e - r * C4;
+        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < HJ) m4 = *reinterpret_cast<const float4*>(mqb + (long)r * C + f * 4);
+        *reinterpret_cast<float4*>(s_m + r * CP + f * 4) = m4;
+    }
+    __syncthreads();
+
+    // ---- scores: thread = (token pair, column group g); columns g + 8 i
+    const int tp = tid >> 3, g = tid & 7;
+    {
+        float acc[2][NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) acc[0][i] = acc[1][i] = 0.f;
+        const float* xa = s_x + (2 * tp) * CP;
+        const float* xb = xa + CP;
+        for (int f = 0; f < ((dbg & 2) ? 1 : C4); ++f) {
+            const float4 a = *reinterpret_cast<const float4*>(xa + f * 4), c4 = *reinterpret_cast<const float4*>(xb + f * 4);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const float4 m4 = *reinterpret_cast<const float4*>(s_m + (g + 8 * i) * CP + f * 4);
+                acc[0][i] += (a.x * m4.x + a.y * m4.y) + (a.z * m4.z + a.w * m4.w);
+                acc[1][i] += (c4.x * m4.x + c4.y * m4.y) + (c4.z * m4.z + c4.w * m4.w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            s_p[(2 * tp) * (HJP + 1) + g + 8 * i] = acc[0][i];
+            s_p[(2 * tp + 1) * (HJP + 1) + g + 8 * i] = acc[1][i];
+        }
+    }
+    __syncthreads();
+    // ---- softmax per (token, head) over the L keys; meanwhile Mo replaces Mq in LDS
+    for (int idx = tid; idx < XT * heads; idx += 256) {
+        const int t = idx / heads, h = idx - t * heads;
+        float* pr = s_p + t * (HJP + 1) + h * L;
+        float mx = -3.4e38f;
+        for (int j = 0; j < L; ++j) mx = fmaxf(mx, pr[j]);
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float e = expf(pr[j] - mx);
+            pr[j] = e;
+            sum += e;
+        }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < L; ++j) pr[j] *= inv;
+    }
+    for (int e = tid; e < HJ * C4; e += 256) {
+        const int r = e / C4, f = e - r * C4;
+        *reinterpret_cast<float4*>(s_m + r * CP + f * 4) = *reinterpret_cast<const float4*>(mob + (long)r * C + f * 4);
+    }
+    __syncthreads();
+
+    // ---- output: thread = (token pair, float4 column group g); float4 columns g + 8 i
+    float4 o[2][NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) o[0][i] = o[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float* pa = s_p + (2 * tp) * (HJP + 1);
+        const float* pb = pa + (HJP + 1);
+        for (int hj = 0; hj < ((dbg & 4) ? 1 : HJ); ++hj) {
+            const float wa = pa[hj], wb = pb[hj];
+            const float* mr = s_m + hj * CP + g * 4;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float4 m4 = *reinterpret_cast<const float4*>(mr + i * 32);
+                o[0][i].x += wa * m4.x; o[0][i].y += wa * m4.y; o[0][i].z += wa * m4.z; o[0][i].w += wa * m4.w;
+                o[1][i].x += wb * m4.x; o[1][i].y += wb * m4.y; o[1][i].z += wb * m4.z; o[1][i].w += wb * m4.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = 2 * tp + u;
+        const bool ok = t < ntok;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = (g + 8 * i) * 4;
+            const float4 bi = *reinterpret_cast<const float4*>(bias + n);
+            float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) xr = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + n);
+            o[u][i].x += bi.x + xr.x; o[u][i].y += bi.y + xr.y; o[u][i].z += bi.z + xr.z; o[u][i].w += bi.w + xr.w;
+            if (ok) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = o[u][i];
+            s += (o[u][i].x + o[u][i].y) + (o[u][i].z + o[u][i].w);
+        }
+        if (n_hi) {
+            // the LayerNorm that follows (norm3 before the feed-forward), written as GEMM operand planes: a token's row is
+            // spread over the 8 lanes of its column groups
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float a0 = o[u][i].x - mean, a1 = o[u][i].y - mean, a2 = o[u][i].z - mean, a3 = o[u][i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            const float rstd = 1.0f / sqrtf(q / (float)C + eps2);
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int n = (g + 8 * i) * 4;
+                    const float4 ga = *reinterpret_cast<const float4*>(gamma2 + n);
+                    const float4 be = *reinterpret_cast<const float4*>(beta2 + n);
+                    float4 y;
+                    y.x = (o[u][i].x - mean) * rstd * ga.x + be.x; y.y = (o[u][i].y - mean) * rstd * ga.y + be.y;
+                    y.z = (o[u][i].z - mean) * rstd * ga.z + be.z; y.w = (o[u][i].w - mean) * rstd * ga.w + be.w;
+                    uint2 hi, lo;
+                    wd_split4(y, hi, lo);
+                    *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + n) = hi;
+                    if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + n) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int NI, int NH>
+int launch_fused(const float* x, int ld, int batch, int hw, const float* gamma, const float* beta, float eps, const float* mq,
+                 const float* mo, int heads, int L, const float* bias, float* out, int out_ld, const float* gamma2,
+                 const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, hipStream_t st) {
+    constexpr int C = NI * 32, CP = C + 4, HJP = NH * 8;
+    constexpr size_t smem = (size_t)(XT * CP + HJP * CP + XT * (HJP + 1)) * sizeof(float);
+    static_assert(smem <= 160 * 1024, "tile does not fit LDS");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<NI, NH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return WD_ELAUNCH;
+        attr = true;
+    }
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    hipLaunchKernelGGL((xattn_fused_kernel<NI, NH>), dim3((hw + XT - 1) / XT, batch), dim3(256), smem, st, x, ld, hw, gamma, beta,
+                       eps, mq, mo, heads, L, bias, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld,
+                       getenv("WDIFF_XATTN_DBG") ? atoi(getenv("WDIFF_XATTN_DBG")) : 0);
+    return wd_check_launch();
+}
+
+
+// ---- MFMA form of the fused kernel: the two products run on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (the
+// normalised tokens and the probabilities from LDS, the folded matrices straight from L2), everything else as above.
+typedef __attribute__((ext_vector_type(8))) __bf16 xa_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float xa_f32x16;
+
+template <int NI>  // c = NI * 32, NI even
+__global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, const wd_bf16* __restrict__ mq_pl,
+                                                         const wd_bf16* __restrict__ mot_pl, int heads, int L,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int out_ld,
+                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                         float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
+                                                         int n_ld) {
+    constexpr int C = NI * 32, C4 = C / 4, XP = C + 8, OP = C + 4, SP = XHJ + 1, PP = XHJ + 8, NT = NI / 2, KSB = C / 16;
+    constexpr int F = (C4 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wd_bf16* sX = reinterpret_cast<wd_bf16*>(smem);                              // [2][XT][XP] normalised tokens (planes)
+    float* sO = reinterpret_cast<float*>(smem);                                   // [XT][OP] output image (overlays sX)
+    constexpr size_t XBYTES = (size_t)2 * XT * XP * 2 > (size_t)XT * OP * 4 ? (size_t)2 * XT * XP * 2 : (size_t)XT * OP * 4;
+    float* sS = reinterpret_cast<float*>(smem + XBYTES);                          // [XT][SP] scores
+    wd_bf16* sP = reinterpret_cast<wd_bf16*>(smem + XBYTES + (size_t)XT * SP * 4);  // [2][XT][PP] probabilities (planes)
+    const int b = blockIdx.y, t0 = blockIdx.x * XT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HJ = heads * L;
+    const long row0 = (long)b * hw + t0;
+    const int ntok = min(XT, hw - t0);
+
+    // ---- all 16 token rows of this wave and the first chunk of the score operand are requested up front (one exposed
+    // memory latency); the raw rows stay in registers for the residual add of the epilogue
+    constexpr int RW = XT / 4;  // rows per wave: wave w owns tokens w*4 + 16*k + u (k, u < 4)
+    float4 xr[RW][F];
+#pragma unroll
+    for (int k = 0; k < RW / 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const int f = lane + 64 * i, t = wave * 4 + 16 * k + u;
+                xr[k * 4 + u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < C4 && t < ntok) xr[k * 4 + u][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + f * 4);
+            }
+    const int rt = wave & 1, cg = wave >> 1;
+    constexpr int CH = 5;  // k-steps per prefetched chunk of the global operand
+    static_assert(KSB % CH == 0 || KSB < CH, "chunking");
+    constexpr int NCH = KSB >= CH ? KSB / CH : 1, CHN = KSB >= CH ? CH : KSB;
+    xa_bf16x8 bh[2][CHN], bl[2][CHN];
+    const wd_bf16* bq = mq_pl + (((long)b * 2) * XHJ + cg * 32 + l31) * C + lh * 8;
+    const bool have_s = cg * 32 < HJ;
+    if (have_s) {
+#pragma unroll
+        for (int i = 0; i < CHN; ++i) {
+            bh[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + i * 16);
+            bl[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + i * 16);
+        }
+    }
+    for (int e = tid; e < 2 * XT * PP / 2; e += 256) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
+    // ---- LayerNorm -> split planes in LDS
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int t = wave * 4 + 16 * (rr / 4) + (rr & 3);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) s += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
+        const float mean = wd_wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            if (f < C4) {
+                const float a0 = xr[rr][i].x - mean, a1 = xr[rr][i].y - mean, a2 = xr[rr][i].z - mean, a3 = xr[rr][i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            if (f < C4) {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
+                const float4 be = *reinterpret_cast<const float4*>(beta + f * 4);
+                float4 o;
+                o.x = (xr[rr][i].x - mean) * rstd * ga.x + be.x; o.y = (xr[rr][i].y - mean) * rstd * ga.y + be.y;
+                o.z = (xr[rr][i].z - mean) * rstd * ga.z + be.z; o.w = (xr[rr][i].w - mean) * rstd * ga.w + be.w;
+                uint2 hi, lo;
+                wd_split4(o, hi, lo);
+                *reinterpret_cast<uint2*>(sX + (long)t * XP + f * 4) = hi;
+                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + f * 4) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- scores S[token][hj] = Xn . Mq^T: wave = (token tile rt, hj tile cg)
+    if (have_s) {
+        xa_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const wd_bf16* ax = sX + (long)(rt * 32 + l31) * XP + lh * 8;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int i = 0; i < CHN; ++i) {
+                    bh[(ch + 1) & 1][i] = *reinterpret_cast<const xa_bf16x8*>(bq + ((ch + 1) * CHN + i) * 16);
+                    bl[(ch + 1) & 1][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((ch + 1) * CHN + i) * 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CHN; ++i) {
+                const int ks = ch * CHN + i;
+                const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ax + ks * 16);
+                const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ax + (long)XT * XP + ks * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ch & 1][i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ch & 1][i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ch & 1][i], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sS[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SP + cg * 32 + l31] = acc[r];
+    }
+    // the operand of the output product does not depend on the softmax: request it now, it lands during the softmax
+    constexpr int KD = 3;  // heads * L <= 40 -> three 16-deep k-steps cover the (head, key) pairs
+    xa_bf16x8 mh[KD][NT], ml[KD][NT];
+    {
+        const wd_bf16* bm = mot_pl + (((long)b * 2) * C + cg * NT * 32 + l31) * XHJ + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                mh[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + (long)t * 32 * XHJ + ks * 16);
+                ml[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + ((long)C + t * 32) * XHJ + ks * 16);
+            }
+    }
+    __syncthreads();
+    // ---- softmax per (token, head) -> probability planes
+    for (int idx = tid; idx < XT * heads; idx += 256) {
+        const int t = idx / heads, h = idx - t * heads;
+        const float* pr = sS + t * SP + h * L;
+        float mx = -3.4e38f;
+        for (int j = 0; j < L; ++j) mx = fmaxf(mx, pr[j]);
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) sum += expf(pr[j] - mx);
+        const float inv = 1.f / sum;
+        for (int j = 0; j < L; ++j) {
+            uint32_t hi, lo;
+            wd_split1(expf(pr[j] - mx) * inv, hi, lo);
+            sP[(long)t * PP + h * L + j] = (wd_bf16)hi;
+            sP[(long)(XT + t) * PP + h * L + j] = (wd_bf16)lo;
+        }
+    }
+    __syncthreads();
+    // ---- output image O[token][n] = P . Mo: wave = (token tile rt, half of the column tiles)
+    {
+        xa_f32x16 o[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        const wd_bf16* ap = sP + (long)(rt * 32 + l31) * PP + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ap + ks * 16);
+            const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ap + (long)XT * PP + ks * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, mh[ks][t], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ml[ks][t], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, mh[ks][t], o[t], 0, 0, 0);
+            }
+        }
+        // (sX is dead: every wave passed the barrier after the score phase)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sO[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * OP + (cg * NT + t) * 32 + l31] = o[t][r];
+    }
+    __syncthreads();
+    // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int t = wave * 4 + 16 * (rr / 4) + (rr & 3);
+        const bool ok = t < ntok;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int f = lane + 64 * i;
+            if (f < C4) {
+                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + f * 4);
+                const float4 bi = *reinterpret_cast<const float4*>(bias + f * 4);
+                xr[rr][i] = make_float4(at.x + bi.x + xr[rr][i].x, at.y + bi.y + xr[rr][i].y, at.z + bi.z + xr[rr][i].z,
+                                        at.w + bi.w + xr[rr][i].w);
+                if (ok) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + f * 4) = xr[rr][i];
+                s += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
+            }
+        }
+        if (n_hi) {
+            const float mean = wd_wave_sum(s) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const int f = lane + 64 * i;
+                if (f < C4) {
+                    const float a0 = xr[rr][i].x - mean, a1 = xr[rr][i].y - mean, a2 = xr[rr][i].z - mean, a3 = xr[rr][i].w - mean;
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)C + eps2);
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < F; ++i) {
+                    const int f = lane + 64 * i;
+                    if (f < C4) {
+                        const float4 ga = *reinterpret_cast<const float4*>(gamma2 + f * 4);
+                        const float4 be = *reinterpret_cast<const float4*>(beta2 + f * 4);
+                        float4 y;
+                        y.x = (xr[rr][i].x - mean) * rstd * ga.x + be.x; y.y = (xr[rr][i].y - mean) * rstd * ga.y + be.y;
+                        y.z = (xr[rr][i].z - mean) * rstd * ga.z + be.z; y.w = (xr[rr][i].w - mean) * rstd * ga.w + be.w;
+                        uint2 hi, lo;
+                        wd_split4(y, hi, lo);
+                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + f * 4) = hi;
+                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + f * 4) = lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NI>
+int launch_mfma(const float* x, int ld, int batch, int hw, const float* gamma, const float* beta, float eps, const wd_bf16* mq_pl,
+                const wd_bf16* mot_pl, int heads, int L, const float* bias, float* out, int out_ld, const float* gamma2,
+                const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, hipStream_t st) {
+    constexpr int C = NI * 32;
+    constexpr size_t xb = (size_t)2 * XT * (C + 8) * 2 > (size_t)XT * (C + 4) * 4 ? (size_t)2 * XT * (C + 8) * 2 : (size_t)XT * (C + 4) * 4;
+    constexpr size_t smem = xb + (size_t)XT * (XHJ + 1) * 4 + (size_t)2 * XT * (XHJ + 8) * 2;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return WD_ELAUNCH;
+        attr = true;
+    }
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    hipLaunchKernelGGL((xattn_mfma_kernel<NI>), dim3((hw + XT - 1) / XT, batch), dim3(256), smem, st, x, ld, hw, gamma, beta, eps,
+                       mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
+    return wd_check_launch();
+}
+
+}  // namespace
+
+extern "C" int wd_xattn_supported(int c, int heads, int L) {
+    return (c == 64 || c == 320) && heads > 0 && L > 0 && heads * L <= 40 && c % heads == 0;
+}
+
+extern "C" int wd_xattn_fold(const float* k, int ldk, const float* v, int ldv, int batch, int heads, int L, int d, float scale,
+                             const float* wq, const float* wo, int c, float* mq, float* mo, wd_bf16* mq_pl, wd_bf16* mot_pl,
+                             void* stream) {
+    if (!k || !v || !wq || !wo || !mq || !mo || batch <= 0 || heads <= 0 || L <= 0 || d <= 0 || c <= 0) return WD_EINVAL;
+    if ((mq_pl != nullptr) != (mot_pl != nullptr) || (mq_pl && heads * L > XHJ)) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(xattn_fold_kernel, dim3(L, heads, batch), dim3(256), 2 * d * sizeof(float), st, k, ldk, v, ldv, heads, L, d,
+                       scale, wq, wo, c, mq, mo, mq_pl, mot_pl);
+    return wd_check_launch();
+}
+
+extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, const float* gamma, const float* beta, float eps,
+                              const float* mq, const float* mo, int heads, int L, const float* bias, float* out, int out_ld,
+                              const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld,
+                              const wd_bf16* mq_pl, const wd_bf16* mot_pl, void* stream) {
+    if (!x || !gamma || !beta || !mq || !mo || !bias || !out || batch <= 0 || hw <= 0) return WD_EINVAL;
+    if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mq_pl && mot_pl && !getenv("WDIFF_XATTN_VALU")) {
+        if (c == 320)
+            return launch_mfma<10>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2,
+                                   eps2, n_hi, n_lo, n_ld, st);
+        return launch_mfma<2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2,
+                              n_hi, n_lo, n_ld, st);
+    }
+    const int nh = (heads * L + 7) / 8;
+#define WD_XA(NI_, NH_)                                                                                                     \
+    return launch_fused<NI_, NH_>(x, ld, batch, hw, gamma, beta, eps, mq, mo, heads, L, bias, out, out_ld, gamma2, beta2, eps2, \
+                                  n_hi, n_lo, n_ld, st)
+    if (c == 320) {
+        switch (nh) {
+            case 1: WD_XA(10, 1);
+            case 2: WD_XA(10, 2);
+            case 3: WD_XA(10, 3);
+            case 4: WD_XA(10, 4);
+            case 5: WD_XA(10, 5);
+        }
+    } else {
+        switch (nh) {
+            case 1: WD_XA(2, 1);
+            case 2: WD_XA(2, 2);
+            case 3: WD_XA(2, 3);
+            case 4: WD_XA(2, 4);
+            case 5: WD_XA(2, 5);
+        }
+    }
+#undef WD_XA
+    return WD_EINVAL;
+}

@@ -261,6 +261,7 @@ class UNetEngine:
         self._w3_meta: Dict[str, tuple] = {}
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
+        self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
@@ -350,6 +351,9 @@ class UNetEngine:
                         kv_w.append(at)
                         self.kv_off[f"{p}.{tag}"] = kvo
                         kvo += 2 * at.to_k.weight.shape[0]
+                        # fp32 copies for the folded cross-attention (wd_xattn_fold)
+                        R.vector(f"{p}.{tag}.q.f32", at.to_q.weight)
+                        R.vector(f"{p}.{tag}.o.f32", at.to_out[0].weight)
                     for tag, at in (("a1", tb.attn1), ("a2", tb.attn2)):
                         R.linear(f"{p}.{tag}.o", at.to_out[0])
                     ffi = tb.ff.net[2].in_features
@@ -639,10 +643,40 @@ class UNetEngine:
         self._gemm(ops, name + ".proj_in", [self._src(g, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
                    out_f32=tok, out_ld=inner)
         xpl = None
+        fuse = self.fuse_xattn and bool(self.lib.wd_xattn_supported(inner, heads, L))
+
+        def folded(tag, p, x_in, x_out, ln_name, next_ln=None):
+            """x_out = x_in + to_out(attention(to_q(LN(x_in)), K, V)) in one launch; K/V/to_q/to_out folded per sample in the
+            conditioning phase (csrc/wd_xattn.hip).  next_ln: also emit the following LayerNorm as operand planes."""
+            ko = self.kv_off[f"{p}.{tag}"]
+            mq = self._f32(P, B, heads * L, inner)
+            mo = self._f32(P, B, heads * L, inner)
+            mq_pl = torch.zeros((B, 2, 64, inner), dtype=torch.bfloat16, device=self.device)   # MFMA operands (padded rows 0)
+            mot_pl = torch.zeros((B, 2, inner, 64), dtype=torch.bfloat16, device=self.device)
+            P.keep += [mq_pl, mot_pl]
+            P.cond.append((self.lib.wd_xattn_fold,
+                           (self._kv.data_ptr() + 4 * ko, self.kv_total, self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, B,
+                            heads, L, d, float(d ** -0.5), self._w[f"{p}.{tag}.q.f32"].data_ptr(),
+                            self._w[f"{p}.{tag}.o.f32"].data_ptr(), inner, mq.data_ptr(), mo.data_ptr(), mq_pl.data_ptr(),
+                            mot_pl.data_ptr()), f"{p}.{tag}:fold"))
+            npl = self._planes(P, M, inner) if next_ln else None
+            ops.append((self.lib.wd_xattn_fused,
+                        (x_in.data_ptr(), inner, B, hw, inner, self._w[f"{p}.{ln_name}.g"].data_ptr(),
+                         self._w[f"{p}.{ln_name}.b"].data_ptr(), 1e-5, mq.data_ptr(), mo.data_ptr(), heads, L,
+                         self._w[f"{p}.{tag}.o.b"].data_ptr(), x_out.data_ptr(), inner,
+                         self._w[f"{p}.{next_ln}.g"].data_ptr() if next_ln else None,
+                         self._w[f"{p}.{next_ln}.b"].data_ptr() if next_ln else None, 1e-5,
+                         npl[0].data_ptr() if next_ln else None,
+                         npl[1].data_ptr() if (next_ln and self.npass == 3) else None, inner, mq_pl.data_ptr(), mot_pl.data_ptr()),
+                        f"{p}.{tag}:folded"))
+            return npl
+
         for di, tb in enumerate(mod.transformer_blocks):
             p = f"{name}.tb{di}"
             scale = d ** -0.5
+            n3 = None
             # ---- attn1
+            tok1 = self._f32(P, M, inner)
             if self.variant == "phosc":
                 n1 = self._ln(P, ops, p + ".norm1", tok, M, inner, p + ".norm1")
                 qkv = self._f32(P, M, 3 * inner)
@@ -651,6 +685,10 @@ class UNetEngine:
                 o1 = self._planes(P, M, inner)
                 self._attention(ops, p + ".a1", qkv.data_ptr(), 3 * inner, qkv.data_ptr() + 4 * inner, 3 * inner,
                                 qkv.data_ptr() + 8 * inner, 3 * inner, heads, hw, hw, d, scale, o1)
+                self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
+                           resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
+            elif fuse:
+                folded("a1", p, tok, tok1, "norm2")  # the base model reads norm2 for both attentions (unet.py:337-345)
             else:
                 n1 = self._ln(P, ops, p + ".norm2a", tok, M, inner, p + ".norm2")
                 q1 = self._f32(P, M, inner)
@@ -659,22 +697,25 @@ class UNetEngine:
                 o1 = self._planes(P, M, inner)
                 self._attention(ops, p + ".a1", q1.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
                                 self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o1)
-            tok1 = self._f32(P, M, inner)
-            self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
-                       resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
+                self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
+                           resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
             # ---- attn2 (cross)
-            n2 = self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
-            q2 = self._f32(P, M, inner)
-            self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
-            ko = self.kv_off[p + ".a2"]
-            o2 = self._planes(P, M, inner)
-            self._attention(ops, p + ".a2", q2.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
-                            self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o2)
             tok2 = self._f32(P, M, inner)
-            self._gemm(ops, p + ".a2.out", [self._src(o2, inner)], p + ".a2.o.w", M, hw, bias=self._w[p + ".a2.o.b"],
-                       resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner)
+            if fuse:
+                n3 = folded("a2", p, tok1, tok2, "norm2", next_ln="norm3")
+            else:
+                n2 = self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
+                q2 = self._f32(P, M, inner)
+                self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
+                ko = self.kv_off[p + ".a2"]
+                o2 = self._planes(P, M, inner)
+                self._attention(ops, p + ".a2", q2.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
+                                self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o2)
+                self._gemm(ops, p + ".a2.out", [self._src(o2, inner)], p + ".a2.o.w", M, hw, bias=self._w[p + ".a2.o.b"],
+                           resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner)
             # ---- GEGLU feed-forward
-            n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
+            if n3 is None:
+                n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
             ffh = self._planes(P, M, 4 * inner)
             self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1.w", M, hw, bias=self._w[p + ".ff1.b"],
                        act=N.ACT_GEGLU, out_pl=ffh, tile=geglu_tile(4 * inner))
