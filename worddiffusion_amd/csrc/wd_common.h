@@ -40,20 +40,25 @@ __device__ __forceinline__ uint32_t wd_f2bf_bits(float x) {  // round-to-nearest
 }
 __device__ __forceinline__ float wd_bf_bits2f(uint32_t b) { return __uint_as_float(b << 16); }
 
+// gfx950 converts fp32 -> bf16 in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, two values per instruction)
+typedef __attribute__((ext_vector_type(2))) float wd_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 wd_bf16x2;
+__device__ __forceinline__ uint32_t wd_pack_bf16x2(float a, float b) {  // a in the low half
+    const wd_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wd_bf16x2));
+}
+
 __device__ __forceinline__ void wd_split1(float x, uint32_t& hi, uint32_t& lo) {
-    hi = wd_f2bf_bits(x);
-    lo = wd_f2bf_bits(x - wd_bf_bits2f(hi));
+    hi = wd_pack_bf16x2(x, 0.f) & 0xffffu;
+    lo = wd_pack_bf16x2(x - __uint_as_float(hi << 16), 0.f) & 0xffffu;
 }
 
 // four floats -> 4 hi (8 bytes) + 4 lo (8 bytes)
 __device__ __forceinline__ void wd_split4(const float4 v, uint2& hi, uint2& lo) {
-    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
-    wd_split1(v.x, h0, l0);
-    wd_split1(v.y, h1, l1);
-    wd_split1(v.z, h2, l2);
-    wd_split1(v.w, h3, l3);
-    hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-    lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    const uint32_t h01 = wd_pack_bf16x2(v.x, v.y), h23 = wd_pack_bf16x2(v.z, v.w);
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(wd_pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)),
+                    wd_pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)));
 }
 
 __device__ __forceinline__ float wd_silu(float x) { return x / (1.0f + expf(-x)); }

@@ -260,8 +260,8 @@ int launch_fused(const float* x, int ld, int batch, int hw, const float* gamma, 
 typedef __attribute__((ext_vector_type(8))) __bf16 xa_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float xa_f32x16;
 
-template <int NI>  // c = NI * 32, NI even
-__global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw,
+template <int NI, int NW>  // c = NI * 32 (NI even); NW waves = 16 * NW tokens per workgroup
+__global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, const wd_bf16* __restrict__ mq_pl,
                                                          const wd_bf16* __restrict__ mot_pl, int heads, int L,
@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
                                                          const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                          float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
                                                          int n_ld) {
+    constexpr int XT = 16 * NW, NTH = 64 * NW, RTN = NW / 2;  // token tiles of 32: RTN; the other wave index picks columns
     constexpr int C = NI * 32, C4 = C / 4, XP = C + 8, OP = C + 4, SP = XHJ + 1, PP = XHJ + 8, NT = NI / 2, KSB = C / 16;
     constexpr int F = (C4 + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
 
     // ---- all 16 token rows of this wave and the first chunk of the score operand are requested up front (one exposed
     // memory latency); the raw rows stay in registers for the residual add of the epilogue
-    constexpr int RW = XT / 4;  // rows per wave: wave w owns tokens w*4 + 16*k + u (k, u < 4)
+    constexpr int RW = 16;  // rows per wave: wave w owns tokens w*4 + 4*NW*k + u (k, u < 4)
     float4 xr[RW][F];
 #pragma unroll
     for (int k = 0; k < RW / 4; ++k)
@@ -294,11 +295,11 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < F; ++i) {
-                const int f = lane + 64 * i, t = wave * 4 + 16 * k + u;
+                const int f = lane + 64 * i, t = wave * 4 + 4 * NW * k + u;
                 xr[k * 4 + u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (f < C4 && t < ntok) xr[k * 4 + u][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + f * 4);
             }
-    const int rt = wave & 1, cg = wave >> 1;
+    const int rt = wave % RTN, cg = wave / RTN;
     constexpr int CH = 5;  // k-steps per prefetched chunk of the global operand
     static_assert(KSB % CH == 0 || KSB < CH, "chunking");
     constexpr int NCH = KSB >= CH ? KSB / CH : 1, CHN = KSB >= CH ? CH : KSB;
@@ -312,11 +313,11 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
             bl[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + i * 16);
         }
     }
-    for (int e = tid; e < 2 * XT * PP / 2; e += 256) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
+    for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
     // ---- LayerNorm -> split planes in LDS
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
-        const int t = wave * 4 + 16 * (rr / 4) + (rr & 3);
+        const int t = wave * 4 + 4 * NW * (rr / 4) + (rr & 3);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < F; ++i) s += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- softmax per (token, head) -> probability planes
-    for (int idx = tid; idx < XT * heads; idx += 256) {
+    for (int idx = tid; idx < XT * heads; idx += NTH) {
         const int t = idx / heads, h = idx - t * heads;
         const float* pr = sS + t * SP + h * L;
         float mx = -3.4e38f;
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
     // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
-        const int t = wave * 4 + 16 * (rr / 4) + (rr & 3);
+        const int t = wave * 4 + 4 * NW * (rr / 4) + (rr & 3);
         const bool ok = t < ntok;
         float s = 0.f;
 #pragma unroll
@@ -486,22 +487,22 @@ __global__ void __launch_bounds__(256) xattn_mfma_kernel(const float* __restrict
     }
 }
 
-template <int NI>
+template <int NI, int NW>
 int launch_mfma(const float* x, int ld, int batch, int hw, const float* gamma, const float* beta, float eps, const wd_bf16* mq_pl,
                 const wd_bf16* mot_pl, int heads, int L, const float* bias, float* out, int out_ld, const float* gamma2,
                 const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, hipStream_t st) {
-    constexpr int C = NI * 32;
-    constexpr size_t xb = (size_t)2 * XT * (C + 8) * 2 > (size_t)XT * (C + 4) * 4 ? (size_t)2 * XT * (C + 8) * 2 : (size_t)XT * (C + 4) * 4;
-    constexpr size_t smem = xb + (size_t)XT * (XHJ + 1) * 4 + (size_t)2 * XT * (XHJ + 8) * 2;
+    constexpr int C = NI * 32, XTM = 16 * NW;
+    constexpr size_t xb = (size_t)2 * XTM * (C + 8) * 2 > (size_t)XTM * (C + 4) * 4 ? (size_t)2 * XTM * (C + 8) * 2 : (size_t)XTM * (C + 4) * 4;
+    constexpr size_t smem = xb + (size_t)XTM * (XHJ + 1) * 4 + (size_t)2 * XTM * (XHJ + 8) * 2;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return WD_ELAUNCH;
         attr = true;
     }
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((xattn_mfma_kernel<NI>), dim3((hw + XT - 1) / XT, batch), dim3(256), smem, st, x, ld, hw, gamma, beta, eps,
+    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW>), dim3((hw + XTM - 1) / XTM, batch), dim3(64 * NW), smem, st, x, ld, hw, gamma, beta, eps,
                        mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
     return wd_check_launch();
 }
@@ -533,9 +534,9 @@ extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mq_pl && mot_pl && !getenv("WDIFF_XATTN_VALU")) {
         if (c == 320)
-            return launch_mfma<10>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2,
+            return launch_mfma<10, 2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2,
                                    eps2, n_hi, n_lo, n_ld, st);
-        return launch_mfma<2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2,
+        return launch_mfma<2, 2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2,
                               n_hi, n_lo, n_ld, st);
     }
     const int nh = (heads * L + 7) / 8;
