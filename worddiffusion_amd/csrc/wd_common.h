@@ -70,6 +70,13 @@ template <int CTRL>
 __device__ __forceinline__ float wd_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+__device__ __forceinline__ float wd_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in all of them
+    v += wd_dpp<0xB1>(v);
+    v += wd_dpp<0x4E>(v);
+    v += wd_dpp<0x124>(v);
+    v += wd_dpp<0x128>(v);
+    return v;
+}
 __device__ __forceinline__ float wd_wave_sum(float v) {
     v += wd_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
     v += wd_dpp<0x4E>(v);   // quad_perm [2,3,0,1]

@@ -271,7 +271,6 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
                                                          int n_ld) {
     constexpr int XT = 16 * NW, NTH = 64 * NW, RTN = NW / 2;  // token tiles of 32: RTN; the other wave index picks columns
     constexpr int C = NI * 32, C4 = C / 4, XP = C + 8, OP = C + 4, SP = XHJ + 1, PP = XHJ + 8, NT = NI / 2, KSB = C / 16;
-    constexpr int F = (C4 + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wd_bf16* sX = reinterpret_cast<wd_bf16*>(smem);                              // [2][XT][XP] normalised tokens (planes)
     float* sO = reinterpret_cast<float*>(smem);                                   // [XT][OP] output image (overlays sX)
@@ -286,19 +285,19 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     const int ntok = min(XT, hw - t0);
 
     // ---- all 16 token rows of this wave and the first chunk of the score operand are requested up front (one exposed
-    // memory latency); the raw rows stay in registers for the residual add of the epilogue
-    constexpr int RW = 16;  // rows per wave: wave w owns tokens w*4 + 4*NW*k + u (k, u < 4)
-    float4 xr[RW][F];
+    // memory latency); the raw rows stay in registers for the residual add of the epilogue.  A row is handled by a
+    // quarter wave (16 lanes x FI float4 each): four rows in flight per wave, reductions stay inside a DPP row.
+    constexpr int FI = NI / 2;  // float4 per lane per row: c / 4 / 16
+    const int qd = lane >> 4, l15 = lane & 15;
+    float4 xr[4][FI];
 #pragma unroll
-    for (int k = 0; k < RW / 4; ++k)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const int f = lane + 64 * i, t = wave * 4 + 4 * NW * k + u;
-                xr[k * 4 + u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < C4 && t < ntok) xr[k * 4 + u][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + f * 4);
-            }
+        for (int i = 0; i < FI; ++i) {
+            const int t = wave * 16 + k * 4 + qd;
+            xr[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
+        }
     const int rt = wave % RTN, cg = wave / RTN;
     constexpr int CH = 5;  // k-steps per prefetched chunk of the global operand
     static_assert(KSB % CH == 0 || KSB < CH, "chunking");
@@ -315,36 +314,36 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     }
     for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
     // ---- LayerNorm -> split planes in LDS
+    {
+        float4 ga[FI], be[FI];
 #pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
-        const int t = wave * 4 + 4 * NW * (rr / 4) + (rr & 3);
-        float s = 0.f;
+        for (int i = 0; i < FI; ++i) {
+            ga[i] = *reinterpret_cast<const float4*>(gamma + (l15 + 16 * i) * 4);
+            be[i] = *reinterpret_cast<const float4*>(beta + (l15 + 16 * i) * 4);
+        }
 #pragma unroll
-        for (int i = 0; i < F; ++i) s += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
-        const float mean = wd_wave_sum(s) / (float)C;
-        float q = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave * 16 + k * 4 + qd;
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < F; ++i) {
-            const int f = lane + 64 * i;
-            if (f < C4) {
-                const float a0 = xr[rr][i].x - mean, a1 = xr[rr][i].y - mean, a2 = xr[rr][i].z - mean, a3 = xr[rr][i].w - mean;
+            for (int i = 0; i < FI; ++i) s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
+            const float mean = wd_row16_sum(s) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
                 q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
-        }
-        const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)C + eps);
+            const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps);
 #pragma unroll
-        for (int i = 0; i < F; ++i) {
-            const int f = lane + 64 * i;
-            if (f < C4) {
-                const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
-                const float4 be = *reinterpret_cast<const float4*>(beta + f * 4);
+            for (int i = 0; i < FI; ++i) {
                 float4 o;
-                o.x = (xr[rr][i].x - mean) * rstd * ga.x + be.x; o.y = (xr[rr][i].y - mean) * rstd * ga.y + be.y;
-                o.z = (xr[rr][i].z - mean) * rstd * ga.z + be.z; o.w = (xr[rr][i].w - mean) * rstd * ga.w + be.w;
+                o.x = (xr[k][i].x - mean) * rstd * ga[i].x + be[i].x; o.y = (xr[k][i].y - mean) * rstd * ga[i].y + be[i].y;
+                o.z = (xr[k][i].z - mean) * rstd * ga[i].z + be[i].z; o.w = (xr[k][i].w - mean) * rstd * ga[i].w + be[i].w;
                 uint2 hi, lo;
                 wd_split4(o, hi, lo);
-                *reinterpret_cast<uint2*>(sX + (long)t * XP + f * 4) = hi;
-                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + f * 4) = lo;
+                *reinterpret_cast<uint2*>(sX + (long)t * XP + (l15 + 16 * i) * 4) = hi;
+                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + (l15 + 16 * i) * 4) = lo;
             }
         }
     }
@@ -437,49 +436,46 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     }
     __syncthreads();
     // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
+    {
+        float4 bi[FI];
 #pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
-        const int t = wave * 4 + 4 * NW * (rr / 4) + (rr & 3);
-        const bool ok = t < ntok;
-        float s = 0.f;
+        for (int i = 0; i < FI; ++i) bi[i] = *reinterpret_cast<const float4*>(bias + (l15 + 16 * i) * 4);
 #pragma unroll
-        for (int i = 0; i < F; ++i) {
-            const int f = lane + 64 * i;
-            if (f < C4) {
-                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + f * 4);
-                const float4 bi = *reinterpret_cast<const float4*>(bias + f * 4);
-                xr[rr][i] = make_float4(at.x + bi.x + xr[rr][i].x, at.y + bi.y + xr[rr][i].y, at.z + bi.z + xr[rr][i].z,
-                                        at.w + bi.w + xr[rr][i].w);
-                if (ok) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + f * 4) = xr[rr][i];
-                s += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave * 16 + k * 4 + qd;
+            const bool ok = t < ntok;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int n = (l15 + 16 * i) * 4;
+                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + n);
+                xr[k][i] = make_float4(at.x + bi[i].x + xr[k][i].x, at.y + bi[i].y + xr[k][i].y, at.z + bi[i].z + xr[k][i].z,
+                                       at.w + bi[i].w + xr[k][i].w);
+                if (ok) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
+                s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
             }
-        }
-        if (n_hi) {
-            const float mean = wd_wave_sum(s) / (float)C;
-            float q = 0.f;
+            if (n_hi) {
+                const float mean = wd_row16_sum(s) / (float)C;
+                float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const int f = lane + 64 * i;
-                if (f < C4) {
-                    const float a0 = xr[rr][i].x - mean, a1 = xr[rr][i].y - mean, a2 = xr[rr][i].z - mean, a3 = xr[rr][i].w - mean;
+                for (int i = 0; i < FI; ++i) {
+                    const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
                     q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
                 }
-            }
-            const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)C + eps2);
-            if (ok) {
+                const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps2);
+                if (ok) {
 #pragma unroll
-                for (int i = 0; i < F; ++i) {
-                    const int f = lane + 64 * i;
-                    if (f < C4) {
-                        const float4 ga = *reinterpret_cast<const float4*>(gamma2 + f * 4);
-                        const float4 be = *reinterpret_cast<const float4*>(beta2 + f * 4);
+                    for (int i = 0; i < FI; ++i) {
+                        const int n = (l15 + 16 * i) * 4;
+                        const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + n);
+                        const float4 b2 = *reinterpret_cast<const float4*>(beta2 + n);
                         float4 y;
-                        y.x = (xr[rr][i].x - mean) * rstd * ga.x + be.x; y.y = (xr[rr][i].y - mean) * rstd * ga.y + be.y;
-                        y.z = (xr[rr][i].z - mean) * rstd * ga.z + be.z; y.w = (xr[rr][i].w - mean) * rstd * ga.w + be.w;
+                        y.x = (xr[k][i].x - mean) * rstd * g2.x + b2.x; y.y = (xr[k][i].y - mean) * rstd * g2.y + b2.y;
+                        y.z = (xr[k][i].z - mean) * rstd * g2.z + b2.z; y.w = (xr[k][i].w - mean) * rstd * g2.w + b2.w;
                         uint2 hi, lo;
                         wd_split4(y, hi, lo);
-                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + f * 4) = hi;
-                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + f * 4) = lo;
+                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + n) = hi;
+                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + n) = lo;
                     }
                 }
             }
