@@ -267,7 +267,8 @@ def main():
                             "command, profiles/r01_pmc_hbm_traffic.json" % (k["fetch_mb_corrected"], k["write_mb"]))
         except (OSError, KeyError, ValueError):
             traffic, traffic_note = None, "no PMC summary under profiles/"
-        roof = dict(bound="mfma", kernel="wd_gemm_kernel<BM,BN,NPASS> (tap-gather MFMA GEMM, all conv/linear layers)",
+        roof = dict(bound="mfma", kernel="wd_gemm2_kernel<128,160,3,2> (tap-gather split-bf16 MFMA GEMM: the 3x3 convolutions, "
+                                         "1x1 / linear projections and GEGLU of the step; hipEvent pair around every launch)",
                     achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_note=traffic_note,
                     launches_per_step=gemm_n // nprof, avg_launch_us=1e3 * gemm_ms / max(gemm_n, 1),
                     algorithmic_gflop_per_step=gemm_flops / nprof / 1e9,

@@ -299,8 +299,9 @@ int wd_graph_launch(void* graph_exec, void* stream);
 int wd_graph_destroy(void* graph_exec);
 
 /* per-kernel-class timing with hipEvents recorded on the launch stream (bench.py roofline leg).
- * classes: 0 gemm, 1 gn_stats, 2 gn_apply, 3 layernorm, 4 attention, 5 other. */
-#define WD_NCLASS 6
+ * classes: 0 gemm (the dominant wd_gemm2_kernel<128,160,...>; gemm_flops counts its 2*M*N*K), 1 gn_stats, 2 gn_apply,
+ * 3 layernorm, 4 attention, 5 other, 6 gemm with other tile shapes, 7 split-K combine pass. */
+#define WD_NCLASS 8
 int wd_prof_enable(int on);
 int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
 

@@ -11,6 +11,8 @@
 #define WD_CLS_LN 3
 #define WD_CLS_ATTN 4
 #define WD_CLS_OTHER 5
+#define WD_CLS_GEMM_OTHER 6   // wd_gemm tile shapes other than the dominant 128x160 kernel
+#define WD_CLS_GEMM_REDUCE 7  // split-K combine pass
 
 // ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
 extern "C" int wd_prof_is_on();

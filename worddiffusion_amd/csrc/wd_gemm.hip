@@ -1006,7 +1006,7 @@ int launch3(const wd_gemm_args& a, hipStream_t st) {
         attr_done = true;
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
-    WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+    WdLaunchScope scope(WD_CLS_GEMM_OTHER, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
     hipLaunchKernelGGL((wd_gemm3_kernel<BM, BN, NPASS, SLABR, KS>), dim3(nbn * nbm), dim3(256 * KS), smem, st, a, nbn,
                        nbm);
     return wd_check_launch();
@@ -1026,7 +1026,7 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
         attr_done = true;
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
-    WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+    WdLaunchScope scope(WD_CLS_GEMM_OTHER, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
     hipLaunchKernelGGL((wd_gemm_kernel<BM, BN, NPASS>), dim3(nbn * nbm), dim3(256), smem, st, a, nbn, nbm);
     return wd_check_launch();
 }
@@ -1079,6 +1079,7 @@ int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
         rattr = true;
     }
     const int rbn = (a.n + RN - 1) / RN, rbm = (a.m + RM - 1) / RM;
+    WdLaunchScope scope(WD_CLS_GEMM_REDUCE, st);
     hipLaunchKernelGGL((wd_gemm_reduce_kernel<RM, RN>), dim3(rbn * rbm), dim3(256), rsmem, st, a, rbn);
     return wd_check_launch();
 }
@@ -1097,9 +1098,12 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
         attr_done = true;
     }
     const int nbn = (a.n + BN - 1) / BN, nbm = (a.m + BM - 1) / BM;
-    WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-    hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS, PP>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
-                       nbn, nbm);
+    {
+        WdLaunchScope scope((BM == 128 && BN == 160) ? WD_CLS_GEMM : WD_CLS_GEMM_OTHER, st,
+                            2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS, PP>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
+                           nbn, nbm);
+    }
     if (a.ksplit > 1) {
         // the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups
         // per tile when the GroupNorm sums are fused in)
