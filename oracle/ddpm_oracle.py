@@ -73,6 +73,44 @@ def sampling(model: Callable, x_T: torch.Tensor, noises: Sequence[torch.Tensor],
     return x
 
 
+def sampling3_calls_model(i: int, noise_steps: int, epoch: int = 0) -> bool:
+    """The predicate of regenerateFromtrain2.py:536 (non-fullSampling): the UNet is evaluated when
+    ``i%100==0 or i%5==0 or i==T or i==T-1 or (epoch>3 and i%25==0) or (epoch>5 and i%15==0) or (epoch>10 and i%10==0) or
+    epoch>50==0`` - the last clause is the chained comparison ``epoch > 50 and 50 == 0`` (always False), the epoch clauses
+    are implied by ``i%5==0``.  Restated literally."""
+    return bool(i % 100 == 0 or i % 5 == 0 or i == noise_steps or i == noise_steps - 1 or (epoch > 3 and i % 25 == 0) or
+                (epoch > 5 and i % 15 == 0) or (epoch > 10 and i % 10 == 0) or (epoch > 50 == 0))
+
+
+def sampling3(model: Callable, x_T: torch.Tensor, noise_steps: int, epoch: int = 0, full_sampling: bool = False,
+              noises: Optional[Sequence[torch.Tensor]] = None):
+    """regenerateFromtrain2.py:521-618 (``sampling3``): the predicted noise is refreshed only on the steps of
+    ``sampling3_calls_model`` and reused in between; without ``fullSampling`` the update drops the noise term
+    (``x = 1/sqrt(alpha) * (x - (1-alpha)/sqrt(1-alpha_hat) * eps)``, :618).  PARITY UNPINNED: the script cannot be imported
+    (its ``unetOriginal`` / ``utils.*`` / ``htr.*`` dependencies are not in the reference), so this restates the published
+    loop and no golden vector exists for it."""
+    beta, alpha, alpha_hat = schedule(noise_steps)
+    x = x_T
+    eps_hat = None
+    k = 0
+    calls = 0
+    for i in reversed(range(1, noise_steps)):
+        t = (torch.ones(x.shape[0]) * i).long()
+        if full_sampling or sampling3_calls_model(i, noise_steps, epoch):
+            eps_hat = model(x, t)
+            calls += 1
+        z = None
+        if full_sampling and i > 1:
+            z = noises[k]
+            k += 1
+        if full_sampling:
+            x = reverse_step(beta, alpha, alpha_hat, x, eps_hat, i, z)
+        else:
+            a, ah = alpha[t][:, None, None, None], alpha_hat[t][:, None, None, None]
+            x = 1 / torch.sqrt(a) * (x - ((1 - a) / (torch.sqrt(1 - ah))) * eps_hat)
+    return x, calls
+
+
 def ema_update(ema_sd: Dict[str, torch.Tensor], sd: Dict[str, torch.Tensor], beta: float, keys) -> None:
     """train.py:151-159: old * beta + (1 - beta) * new, parameters only."""
     for k in keys:

@@ -3,6 +3,7 @@ UNet forwards against the reference's golden outputs and the oracle, the DDPM tr
 recorded-noise trajectory, and size-independent properties at the benchmark size (B=64).
 Tolerance: 1e-3 relative to the fp32 reference (BASELINE.json north_star); the split-bf16 path sits ~1e-5."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -510,3 +511,42 @@ def test_phosc_training_gradients_match_oracle_autograd(cfg_name, B, hw, phosc_l
         r = ref.grad.double()
         err = float((gr.detach().cpu().double() - r).norm())
         assert err < 2e-4 * float(r.norm()) + 1e-7, (k, err, float(r.norm()))
+
+
+def test_step_skipping_sampler_and_bulk_driver(tmp_path):
+    """Diffusion.sampling3 (regenerateFromtrain2.py:465-648: predicted noise refreshed 1 step in 5, deterministic update)
+    against the oracle's restatement of that loop; then the bulk driver: rows sharded over 2 "ranks" and small batches give
+    the same latents as one big call (global-row-indexed noise)."""
+    from worddiffusion_amd.driver import regenerate, writer_dict
+    T = 23
+    m = build(SMALL, "base", False, seed=3)
+    args = make_args(device=DEV)
+    args.fullSampling = False
+    diff = Diffusion(noise_steps=T, img_size=(32, 64), args=args)
+    words = ["MOVE", "a", "Zebra"]
+    labels = torch.tensor([1, 4, 7], dtype=torch.int64)
+    x_t = torch.randn(3, 4, 4, 8, generator=torch.Generator().manual_seed(8))
+    got = diff.sampling3(0, x_t.to(DEV), words, None, m, m, None, 0, 0, 3, words, labels.to(DEV), args)
+    assert diff.last_stats["model_calls"] == len([i for i in range(1, T) if i % 5 == 0 or i == T - 1])
+    # oracle loop on the CPU
+    shapes = U.state_dict_shapes(SMALL, "base")
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, 3)) for k, s in shapes}
+    orc = U.UNetOracle(SMALL, sd, "base", False)
+    tf = torch.tensor(np.array([D.label_padding(w) for w in words], dtype="int64"))
+    with torch.no_grad():
+        ref, calls = D.sampling3(lambda x, t: orc(x, t, tf, labels), x_t, T)
+    assert calls == diff.last_stats["model_calls"]
+    assert max_rel(got.cpu(), ref) < 2e-4
+    # ---- bulk driver: 5 rows, batch 2, two ranks == one call over all rows
+    rows = [("w1", "img0", "MOVE"), ("w2", "img1", "to"), ("w1", "img2", "a"), ("w3", "img3", "Stop"), ("w2", "img4", "it")]
+    wr = writer_dict(rows)
+    diff2 = Diffusion(noise_steps=9, img_size=(32, 64), args=args)
+    _, whole = regenerate(m, diff2, rows, wr, args, batch=8, seed=5, rank=0, world=1)
+    parts = []
+    for r in range(2):
+        s0, part = regenerate(m, diff2, rows, wr, args, batch=2, seed=5, rank=r, world=2, out_dir=str(tmp_path))
+        parts.append(part)
+    assert max_rel(torch.cat(parts), whole) < 1e-5
+    assert sorted(os.listdir(tmp_path)) == [f"img{i}.npy" for i in range(5)]
+    assert np.allclose(np.load(tmp_path / "img3.npy"), whole[3].numpy(), atol=1e-5)

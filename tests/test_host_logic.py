@@ -154,3 +154,35 @@ def test_no_cpu_fallback():
     x = torch.zeros(1, 4, 4, 8)
     with torch.no_grad(), pytest.raises(N.NativeError):
         m(x, None, timesteps=torch.tensor([3]), context=torch.zeros(1, 10, dtype=torch.long), y=torch.tensor([0]))
+
+
+def test_driver_host_pieces(tmp_path):
+    """gt reader / writer dictionary / PNG writer of the bulk sampling driver (full_sampling.py:132-153)."""
+    import struct
+    import zlib
+    from worddiffusion_amd.driver import read_gt, write_png, writer_dict
+    gt = tmp_path / "gt.txt"
+    gt.write_text("000,a01-000u-00-00 A\n011,a01-000u-00-01 MOVE\n000,a01-000u-00-02 to\n\nbroken-line\n")
+    rows = read_gt(str(gt))
+    assert rows == [("000", "a01-000u-00-00", "A"), ("011", "a01-000u-00-01", "MOVE"), ("000", "a01-000u-00-02", "to")]
+    assert writer_dict(rows) == {"000": 0, "011": 1}
+    wj = tmp_path / "writers.json"
+    wj.write_text('{"000": 7, "011": 3}')
+    assert writer_dict(rows, str(wj)) == {"000": 7, "011": 3}
+    img = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    p = tmp_path / "x.png"
+    write_png(str(p), img)
+    data = p.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h, depth, color = struct.unpack(">IIBB", data[16:26])
+    assert (w, h, depth, color) == (7, 5, 8, 2)
+    i0 = data.index(b"IDAT")
+    n = struct.unpack(">I", data[i0 - 4:i0])[0]
+    raw = zlib.decompress(data[i0 + 4:i0 + 4 + n])
+    rows_px = np.frombuffer(raw, dtype=np.uint8).reshape(5, 1 + 7 * 3)
+    assert (rows_px[:, 0] == 0).all() and np.array_equal(rows_px[:, 1:].reshape(5, 7, 3), img)
+    # the step-skipping predicate: T-1 and every multiple of 5
+    from oracle import ddpm_oracle as D
+    calls = [i for i in range(1, 600) if D.sampling3_calls_model(i, 600, epoch=12)]
+    assert calls == [i for i in range(1, 600) if i % 5 == 0 or i == 599]
+    assert all(Diffusion.sampling3_calls_model(i, 600, 12) == D.sampling3_calls_model(i, 600, 12) for i in range(1, 600))

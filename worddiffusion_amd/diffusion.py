@@ -126,7 +126,7 @@ class Diffusion:
 
     # --------------------------------------------------------------------------------------------------
     def _denoise(self, model, n, text_features, labels, phosc, device, x_T=None, noise=None, seed=None,
-                 sample_offset=0, record=None, use_graph=True):
+                 sample_offset=0, record=None, use_graph=True, calls_model=None, deterministic=False):
         lib = N.lib()
         eng = model.engine
         eng.refresh_weights()
@@ -135,6 +135,8 @@ class Diffusion:
         phosc_len = 0 if phosc is None else phosc.shape[1]
         P = eng.plan(n, h, w, ctx_len, phosc_len)
         ca, cb, cs = self._step_tables(device)
+        if deterministic:  # regenerateFromtrain2.py:618 drops the sqrt(beta) * noise term
+            cs = torch.zeros_like(cs)
         T = self.noise_steps
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         npix = P.x_in[0].numel()
@@ -154,43 +156,54 @@ class Diffusion:
             zbuf = torch.zeros_like(P.x_in) if noise is not None else None
             P.run_cond(st)
 
-            def one_step(stream):
-                for _ in range(self.forwards_per_step):
-                    P.run_step(stream)
+            def one_step(stream, forward=True):
+                if forward:
+                    for _ in range(self.forwards_per_step):
+                        P.run_step(stream)
                 N.check(lib.wd_ddpm_step(P.x_in.data_ptr(), P.out.data_ptr(), n, npix, ca.data_ptr(), cb.data_ptr(),
                                          cs.data_ptr(), t_dev.data_ptr(), zbuf.data_ptr() if zbuf is not None else None,
                                          seed, sample_offset, stream), "wd_ddpm_step")
                 N.check(lib.wd_advance_timestep(t_dev.data_ptr(), -1, P.t_in.data_ptr(), n, stream),
                         "wd_advance_timestep")
 
-            gexec = None
-            if use_graph and record is None:
+            def capture(forward):
                 N.check(lib.wd_graph_begin(st), "wd_graph_begin")
                 try:
-                    one_step(st)
+                    one_step(st, forward)
                 finally:
                     g = C.c_void_p()
                     rc = lib.wd_graph_end(st, C.byref(g))
                 N.check(rc, "wd_graph_end")
-                gexec = g
+                return g
+
+            gexec = gskip = None
+            if use_graph and record is None:
+                gexec = capture(True)
+                if calls_model is not None:
+                    gskip = capture(False)  # steps that reuse the previous predicted noise: update only
             k = 0
+            ncalls = 0
             for i in reversed(range(1, T)):
                 if record is not None:
                     record.append(P.x_in.clone())
                 if zbuf is not None and i > 1:
                     zbuf.copy_(noise[k].to(device))
                     k += 1
+                fwd = calls_model is None or bool(calls_model(i))
+                ncalls += int(fwd)
                 if gexec is not None:
-                    N.check(lib.wd_graph_launch(gexec, st), "wd_graph_launch")
+                    N.check(lib.wd_graph_launch(gexec if fwd else gskip, st), "wd_graph_launch")
                 else:
-                    one_step(st)
+                    one_step(st, fwd)
             x = P.x_in.clone()
         torch.cuda.current_stream(device).wait_stream(side)
         if gexec is not None:
             side.synchronize()
             lib.wd_graph_destroy(gexec)
+            if gskip is not None:
+                lib.wd_graph_destroy(gskip)
         self.last_stats = dict(steps=T - 1, forwards_per_step=self.forwards_per_step, graph=gexec is not None,
-                               seed=seed, sample_offset=sample_offset)
+                               seed=seed, sample_offset=sample_offset, model_calls=ncalls)
         return x
 
     def _text_features(self, x_text, n):
@@ -241,6 +254,54 @@ class Diffusion:
         return self._finish(x, vae, args)
 
     sample = sampling  # sampling.py:119 / full_sampling.py:167 call .sample(...)
+
+    @staticmethod
+    def sampling3_calls_model(i, noise_steps, epoch=0):
+        """The step-skipping predicate of ``regenerateFromtrain2.py:536`` (literal; its last clause ``epoch>50==0`` is a
+        chained comparison that is always False): the UNet runs at ``i == T-1`` and whenever ``i % 5 == 0``."""
+        return bool(i % 100 == 0 or i % 5 == 0 or i == noise_steps or i == noise_steps - 1 or (epoch > 3 and i % 25 == 0) or
+                    (epoch > 5 and i % 15 == 0) or (epoch > 10 and i % 10 == 0) or (epoch > 50 == 0))
+
+    @torch.no_grad()
+    def sampling3(self, epoch, x_t, words, phoscLabels, model, model1, vae, emaOld, noiseInput, n, x_text, labels, args,
+                  mix_rate=None, cfg_scale=3, seed=None, sample_offset=0, use_graph=True):
+        """Bulk-regeneration sampler of ``regenerateFromtrain2.py:465-648`` (same argument order): the predicted noise is
+        refreshed only on the steps of ``sampling3_calls_model`` (1 in 5) and reused in between, and unless
+        ``args.fullSampling`` the update is deterministic (no ``sqrt(beta) * noise`` term, ``:618``).  ``noiseInput == 0``
+        starts from ``x_t`` instead of fresh noise (``:518-519``).  Returns ``(0, [images], images)`` like the reference when
+        a ``vae`` is given, the denoised latents otherwise.  The per-step ``flagGen.txt`` poll (``:523-530``) is not
+        reproduced.  Parity: restated loop, no reference vector exists (the script is not importable) - see the oracle."""
+        if mix_rate is not None:
+            raise NotImplementedError("mix_rate interpolation (unet.py:1558-1573)")
+        if emaOld == 1:
+            model = model1
+        was_training = model.training
+        model.eval()
+        device = torch.device(getattr(args, "device", self.device))
+        if device.type != "cuda":
+            raise N.NativeError("Diffusion.sampling3 runs on an MI355X only (no CPU fallback)")
+        if isinstance(x_text, str) or len(x_text) <= 1:
+            word_list = [x_text if isinstance(x_text, str) else x_text[0]] * n
+        else:
+            word_list = list(words)
+        tf = self._text_features(word_list, n)
+        phosc = None
+        if getattr(args, "phosc", 0) == 1 or getattr(args, "phos", 0) == 1:
+            if phoscLabels is None:
+                raise ValueError("args.phosc/phos set but phoscLabels missing")
+            phosc = phoscLabels.int()
+        full = bool(getattr(args, "fullSampling", False))
+        T = self.noise_steps
+        x = self._denoise(model, n, tf, labels, phosc, device, x_T=x_t if noiseInput == 0 else None, seed=seed,
+                          sample_offset=sample_offset, use_graph=use_graph,
+                          calls_model=None if full else (lambda i: self.sampling3_calls_model(i, T, epoch)),
+                          deterministic=not full)
+        if was_training:
+            model.train()
+        if vae is None:
+            return x
+        image = self._finish(x, vae, args)
+        return 0, [image], image
 
     def sampling_modify_condition(self, model, vae, latents, x_text, words, n, labels, args, **kw):
         """Argument order of ``trainModifyCondition.py:545``; that variant feeds writer id 1 for every sample
