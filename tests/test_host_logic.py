@@ -186,3 +186,28 @@ def test_driver_host_pieces(tmp_path):
     calls = [i for i in range(1, 600) if D.sampling3_calls_model(i, 600, epoch=12)]
     assert calls == [i for i in range(1, 600) if i % 5 == 0 or i == 599]
     assert all(Diffusion.sampling3_calls_model(i, 600, 12) == D.sampling3_calls_model(i, 600, 12) for i in range(1, 600))
+
+
+def test_phosc_descriptors_match_reference_golden(golden_dir, tmp_path):
+    """PHOS / PHOC / PHOSC vectors against the outputs of the reference's own generators (tests/golden/phosc.npz, made by
+    oracle/make_golden_phosc.py); the shape-count table travels as data inside the golden file."""
+    from worddiffusion_amd.phosc import load_alphabet, phoc_vector, phos_vector, phosc_vector
+    g = load_golden(golden_dir, "phosc")
+    for version in ("eng", "gw", "nor"):
+        letters = [str(x) for x in g[f"{version}:letters"]]
+        table = g[f"{version}:table"]
+        index = {k: i for i, k in enumerate(letters)}  # later rows win, as in create_alphabet_dictionary
+        for w, ph, pc in zip(g[f"{version}:words"], g[f"{version}:phos"], g[f"{version}:phoc"]):
+            w = str(w)
+            assert np.array_equal(phos_vector(w, index, table), ph), (version, w)
+            assert phoc_vector(w, version) == [int(v) for v in pc], (version, w)
+            full = phosc_vector(w, index, table, version)
+            assert full.dtype == np.int64 and np.array_equal(full, np.concatenate([ph, pc]).astype(np.int64))
+        # csv round trip of the loader (same parse as the reference: first column = letter)
+        p = tmp_path / f"{version}.csv"
+        p.write_text("\n".join(",".join([k] + [str(int(v)) for v in row]) for k, row in zip(letters, table)))
+        idx2, tab2 = load_alphabet(str(p))
+        assert idx2 == index and np.array_equal(tab2, table)
+    assert len(phosc_vector("Stop", {k: i for i, k in enumerate(str(x) for x in g["eng:letters"])}, g["eng:table"])) == 769
+    with pytest.raises(KeyError):
+        phos_vector("é", {"a": 0}, np.zeros((1, 11), dtype=int))
