@@ -550,3 +550,30 @@ def test_step_skipping_sampler_and_bulk_driver(tmp_path):
     assert max_rel(torch.cat(parts), whole) < 1e-5
     assert sorted(os.listdir(tmp_path)) == [f"img{i}.npy" for i in range(5)]
     assert np.allclose(np.load(tmp_path / "img3.npy"), whole[3].numpy(), atol=1e-5)
+
+
+def test_training_in_single_pass_bf16_mode():
+    """set_precision('bf16') (single MFMA pass, fp32 master weights / accumulation) also drives the training plan: gradients
+    agree with the split-bf16 ones to bf16 accuracy (a few 1e-2) - reported separately from the parity mode."""
+    cfg, B, hw = SMALL, 4, (8, 32)
+    inp = synthetic_inputs(B, seed=43, hw=hw, num_classes=cfg["num_classes"])
+    eps = torch.from_numpy(np.random.RandomState(44).standard_normal(tuple(inp["x"].shape)).astype(np.float32)).to(DEV)
+    m = UNetModel(args=make_args(device=DEV), **cfg)
+    fill_module_(m, 12)
+    m = m.to(DEV).train()
+    args = dict(timesteps=inp["t"].to(DEV), context=inp["context"].to(DEV), y=inp["y"].to(DEV))
+    grads = {}
+    for mode in ("bf16x3", "bf16"):
+        m.set_precision(mode)
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.MSELoss()(eps, m(inp["x"].to(DEV), **args)).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.set_precision("bf16x3")
+    worst = 0.0
+    for k, g in grads["bf16x3"].items():
+        if g.numel() < 64 or float(g.norm()) < 1e-6:
+            continue
+        worst = max(worst, rel_err(grads["bf16"][k].cpu(), g.cpu()))
+    assert 1e-4 < worst < 0.15, worst

@@ -164,7 +164,10 @@ class UNetBase(nn.Module):
 
     def set_precision(self, mode: str):
         """'bf16x3' (default; split-bf16 MFMA, fp32-class results) or 'bf16' (single pass)."""
+        self.__dict__["_precision"] = mode
         self.engine.set_precision(mode)
+        if self._train_engine is not None:
+            self._train_engine.set_precision(mode)
         return self
 
     def convert_to_fp16(self):  # no-ops in the reference as well (unet.py:415-419)
@@ -188,7 +191,7 @@ class UNetBase(nn.Module):
         if self._train_engine is None:
             from .train_engine import TrainEngine
             self._train_engine = TrainEngine(self, self.variant)
-            mode = os.environ.get("WDIFF_PRECISION")
+            mode = self.__dict__.get("_precision") or os.environ.get("WDIFF_PRECISION")
             if mode:
                 self._train_engine.set_precision(mode)
         return self._train_engine

@@ -63,6 +63,13 @@ class TrainEngine(UNetEngine):
         self._arena = None
         self._arena_used = 0
 
+    def set_precision(self, mode: str):
+        old = self.npass
+        super().set_precision(mode)
+        if self.npass != old and self._tplans:
+            self._tplans.clear()
+            self._scr = {k: v for k, v in self._scr.items() if isinstance(k, tuple)}
+
     # ------------------------------------------------------------------------------------------ weights
     def _recipes(self):
         R = super()._recipes()
