@@ -265,6 +265,17 @@ int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, con
                            int ldo, int batch, int heads, int nq, int nk, int d, float scale, float* dq, int lddq,
                            float* dkv_part, int* nwg_out, void* stream);
 
+/* One pass over d(output) [m][n] fp32 (row pitch ld) producing what the layer's backward consumes; each output optional:
+ *  pl_*   row-major split planes [m][npad] (columns n..npad-1 zero) - operand of the data-gradient GEMM;
+ *  t_*    transposed split planes [n][mpad] (columns m..mpad-1 zero) - operand of the weight-gradient GEMM;
+ *  colpart[ceil(mpad/64)][n] column sums of every 64-row block - wd_colsum_finish(colpart, nblk, n, nseg, ...) then sums
+ *  nblk consecutive blocks per segment (bias gradient: one segment; FiLM gradient: one segment per sample). */
+int wd_dout_prep_rows(void);
+int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf16* pl_hi, wd_bf16* pl_lo, wd_bf16* t_hi,
+                 wd_bf16* t_lo, float* colpart, void* stream);
+int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate, float scale,
+                     void* stream);
+
 /* Attention backward for any number of keys <= 1024 (spatial self-attention, the 779-token PHOSC context): recomputes the
  * softmax rows, dq/dk/dv written in place of autograd's (row pitches ldd*; head h owns columns [h*d, (h+1)*d)).
  * scratch: wd_attention_bwd_scratch_floats() floats (P and dS, [batch][heads][nq][nk] each).  Deterministic. */

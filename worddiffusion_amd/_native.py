@@ -73,6 +73,9 @@ _SIGS = {
     "wd_xattn_supported": (_i, [_i, _i, _i]),
     "wd_xattn_fold": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "wd_xattn_fused": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
+    "wd_dout_prep_rows": (_i, []),
+    "wd_dout_prep": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wd_colsum_finish": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, _vp]),
     "wd_add": (_i, [_vp, _vp, C.c_int64, _vp]),
     "wd_permute_dw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wd_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, C.c_int64, _vp]),

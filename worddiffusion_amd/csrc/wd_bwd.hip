@@ -23,43 +23,140 @@ __device__ __forceinline__ float gelu_grad(float g) {  // d gelu_erf(g) / dg
 }
 
 // ---- transpose: out[(t*C + c)][m] = in[src(m, t)][c]   (64 x 64 tiles through LDS; src = gather table or identity)
+// plane input: 8-byte loads (4 channels) and 8-byte stores (4 tokens) per thread and plane
 template <bool F32IN>
 __global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __restrict__ in_hi, const void* __restrict__ in_lo,
                                                                int ld, int c, const int32_t* __restrict__ gather, int ntaps,
                                                                int hw_out, int hw_src, int m, int mpad, int tap_minor,
                                                                wd_bf16* __restrict__ out_hi, wd_bf16* __restrict__ out_lo) {
-    __shared__ wd_bf16 th[64][66], tl[64][66];
+    __shared__ wd_bf16 th[64][68], tl[64][68];  // [token][channel]
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-    for (int r = ty; r < 64; r += 4) {       // r: token inside the tile, tx: channel
-        const int mm = m0 + r, cc = c0 + tx;
-        uint32_t h = 0, l = 0;
-        if (mm < m && cc < c) {
-            long src = mm;
-            if (gather) {
-                const int b = mm / hw_out, p = mm - b * hw_out;
-                const int g = gather[tap * hw_out + p];
-                src = g >= 0 ? (long)b * hw_src + g : -1;
+    const int tid = threadIdx.x;
+    {
+        const int q = tid & 15, r4 = tid >> 4;  // q: channel quad, r4: 16 token rows per pass
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = r4 + 16 * ps;
+            const int mm = m0 + r, cc = c0 + q * 4;
+            uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+            if (mm < m && cc < c) {
+                long src = mm;
+                if (gather) {
+                    const int b = mm / hw_out, p = mm - b * hw_out;
+                    const int g = gather[tap * hw_out + p];
+                    src = g >= 0 ? (long)b * hw_src + g : -1;
+                }
+                if (src >= 0) {
+                    if (F32IN) {
+                        const float* xp = reinterpret_cast<const float*>(in_hi) + src * ld + cc;
+                        if (cc + 3 < c && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)) {
+                            wd_split4(*reinterpret_cast<const float4*>(xp), h, l);
+                        } else {
+                            float4 v = make_float4(xp[0], cc + 1 < c ? xp[1] : 0.f, cc + 2 < c ? xp[2] : 0.f, cc + 3 < c ? xp[3] : 0.f);
+                            wd_split4(v, h, l);
+                        }
+                    } else {
+                        const wd_bf16* hp = reinterpret_cast<const wd_bf16*>(in_hi) + src * ld + cc;
+                        const wd_bf16* lp = in_lo ? reinterpret_cast<const wd_bf16*>(in_lo) + src * ld + cc : nullptr;
+                        if (cc + 3 < c && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(hp) & 7) == 0) &&
+                            (!lp || (reinterpret_cast<uintptr_t>(lp) & 7) == 0)) {
+                            h = *reinterpret_cast<const uint2*>(hp);
+                            if (lp) l = *reinterpret_cast<const uint2*>(lp);
+                        } else {
+                            uint32_t e[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0};
+                            for (int u = 0; u < 4; ++u)
+                                if (cc + u < c) {
+                                    e[u] = hp[u];
+                                    if (lp) f[u] = lp[u];
+                                }
+                            h = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                            l = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
+                        }
+                    }
+                }
             }
-            if (src >= 0) {
-                if (F32IN) {
-                    wd_split1(reinterpret_cast<const float*>(in_hi)[src * ld + cc], h, l);
-                } else {
-                    h = reinterpret_cast<const wd_bf16*>(in_hi)[src * ld + cc];
-                    if (in_lo) l = reinterpret_cast<const wd_bf16*>(in_lo)[src * ld + cc];
+            *reinterpret_cast<uint2*>(&th[r][q * 4]) = h;
+            *reinterpret_cast<uint2*>(&tl[r][q * 4]) = l;
+        }
+    }
+    __syncthreads();
+    {
+        const int mq = tid & 15, c4 = tid >> 4;  // mq: token quad, c4: 16 channel rows per pass
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = c4 + 16 * ps;          // channel inside the tile
+            const int cc = c0 + r, mm = m0 + mq * 4;
+            if (cc < c && mm < mpad) {
+                const long o = (tap_minor ? (long)cc * ntaps + tap : (long)tap * c + cc) * mpad + mm;
+                const uint32_t a0 = th[mq * 4][r], a1 = th[mq * 4 + 1][r], a2 = th[mq * 4 + 2][r], a3 = th[mq * 4 + 3][r];
+                *reinterpret_cast<uint2*>(out_hi + o) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+                if (out_lo) {
+                    const uint32_t b0 = tl[mq * 4][r], b1 = tl[mq * 4 + 1][r], b2 = tl[mq * 4 + 2][r], b3 = tl[mq * 4 + 3][r];
+                    *reinterpret_cast<uint2*>(out_lo + o) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
                 }
             }
         }
-        th[r][tx] = (wd_bf16)h;
-        tl[r][tx] = (wd_bf16)l;
+    }
+}
+
+// ---- one pass over d(output) [M][n] fp32 for everything its layer's backward needs: row-major split planes (operand of the
+// data-gradient GEMM), transposed split planes (operand of the weight-gradient GEMM) and per-64-row column sums (bias /
+// FiLM gradients after wd_colsum_finish).  Any of the three outputs may be NULL.
+__global__ void __launch_bounds__(256) dout_prep_kernel(const float* __restrict__ d, int ld, int m, int n, int npad, int mpad,
+                                                        wd_bf16* __restrict__ pl_hi, wd_bf16* __restrict__ pl_lo,
+                                                        wd_bf16* __restrict__ t_hi, wd_bf16* __restrict__ t_lo,
+                                                        float* __restrict__ colpart) {
+    __shared__ wd_bf16 th[64][68], tl[64][68];
+    __shared__ float cs[16][65];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const int q = tid & 15, r4 = tid >> 4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int r = r4 + 16 * ps;
+        const int mm = m0 + r, cc = c0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mm < m && cc < n) {
+            const float* xp = d + (long)mm * ld + cc;
+            if (cc + 3 < n) v = *reinterpret_cast<const float4*>(xp);
+            else v = make_float4(xp[0], cc + 1 < n ? xp[1] : 0.f, cc + 2 < n ? xp[2] : 0.f, 0.f);
+        }
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        uint2 h, l;
+        wd_split4(v, h, l);
+        *reinterpret_cast<uint2*>(&th[r][q * 4]) = h;
+        *reinterpret_cast<uint2*>(&tl[r][q * 4]) = l;
+        if (pl_hi && mm < m && cc < npad) {  // (columns n..npad-1 of the row-major planes are written as zeros)
+            *reinterpret_cast<uint2*>(pl_hi + (long)mm * npad + cc) = h;
+            if (pl_lo) *reinterpret_cast<uint2*>(pl_lo + (long)mm * npad + cc) = l;
+        }
+    }
+    if (colpart) {
+        cs[r4][q * 4 + 0] = sum.x; cs[r4][q * 4 + 1] = sum.y; cs[r4][q * 4 + 2] = sum.z; cs[r4][q * 4 + 3] = sum.w;
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {       // r: channel inside the tile, tx: token
-        const int cc = c0 + r, mm = m0 + tx;
-        if (cc < c && mm < mpad) {
-            const long o = (tap_minor ? (long)cc * ntaps + tap : (long)tap * c + cc) * mpad + mm;
-            out_hi[o] = th[tx][r];
-            if (out_lo) out_lo[o] = tl[tx][r];
+    if (colpart && tid < 64 && c0 + tid < n) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += cs[k][tid];
+        colpart[(long)blockIdx.x * n + c0 + tid] = a;
+    }
+    if (t_hi) {
+        const int mq = tid & 15, c4 = tid >> 4;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = c4 + 16 * ps;
+            const int cc = c0 + r, mm = m0 + mq * 4;
+            if (cc < n && mm < mpad) {
+                const long o = (long)cc * mpad + mm;
+                const uint32_t a0 = th[mq * 4][r], a1 = th[mq * 4 + 1][r], a2 = th[mq * 4 + 2][r], a3 = th[mq * 4 + 3][r];
+                *reinterpret_cast<uint2*>(t_hi + o) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+                if (t_lo) {
+                    const uint32_t b0 = tl[mq * 4][r], b1 = tl[mq * 4 + 1][r], b2 = tl[mq * 4 + 2][r], b3 = tl[mq * 4 + 3][r];
+                    *reinterpret_cast<uint2*>(t_lo + o) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+                }
+            }
         }
     }
 }
@@ -878,5 +975,29 @@ extern "C" int wd_attention_bwd(const float* q, int ldq, const float* k, int ldk
                        ldo, heads, nq, nk, d, scale, dq, lddq, pbuf, dsbuf, rows);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, q, ldq, dout, ldo, heads, nq, nk,
                        d, pbuf, dsbuf, dk, lddk, dv, lddv, cols);
+    return wd_check_launch();
+}
+
+extern "C" int wd_dout_prep_rows(void) { return 64; }
+
+extern "C" int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf16* pl_hi, wd_bf16* pl_lo,
+                            wd_bf16* t_hi, wd_bf16* t_lo, float* colpart, void* stream) {
+    if (!d || m <= 0 || n <= 0 || npad < n || mpad < m || (mpad & 3) || (npad & 3) || (ld & 3)) return WD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d) & 15) || (!pl_hi && !t_hi && !colpart)) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    const int ncols = pl_hi ? npad : n;
+    hipLaunchKernelGGL(dout_prep_kernel, dim3((mpad + 63) / 64, (ncols + 63) / 64), dim3(256), 0, st, d, ld, m, n, npad, mpad,
+                       pl_hi, pl_lo, t_hi, t_lo, colpart);
+    return wd_check_launch();
+}
+
+extern "C" int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate,
+                                float scale, void* stream) {
+    if (!part || !out || nblk <= 0 || c <= 0 || nseg <= 0) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 63) / 64, nseg), dim3(256), 0, st, part, nblk, c, nseg, out, out_ld, accumulate,
+                       scale);
     return wd_check_launch();
 }

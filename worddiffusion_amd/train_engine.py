@@ -245,18 +245,23 @@ class TrainEngine(UNetEngine):
         mpad = _rup(M, 64)
         lo_ok = self.npass == 3
         need_dx = any(s.get("dx") for s in segs)
-        if need_dx:
-            if ldd == npad:
-                dpl = self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)[: 2 * M * npad].view(2, M, npad)
-            else:
-                raise AssertionError(what)
-            ops.append((lib.wd_split, (dout.data_ptr(), ldd, M, npad, 0, dpl[0].data_ptr(),
-                                       dpl[1].data_ptr() if lo_ok else None, npad), what + ":split(dout)"))
         need_dw = any(s.get("wgrad") is not None or s.get("wgrad_packed") is not None for s in segs)
+        dpl = doutT = colpart = None
+        if need_dx:
+            dpl = self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)[: 2 * M * npad].view(2, M, npad)
         if need_dw:
             doutT = self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)[: 2 * n * mpad].view(2, n, mpad)
-            ops.append((lib.wd_transpose_planes, (dout.data_ptr(), None, 1, ldd, n, None, 1, 0, 0, M, mpad, 0,
-                                                  doutT[0].data_ptr(), doutT[1].data_ptr()), what + ":T(dout)"))
+        # bias / FiLM gradients come out of the same pass as per-64-row column sums whenever the segments line up
+        fuse_cs = (bool(bias) or film_off is not None) and (film_off is None or hw_out % 64 == 0)
+        if fuse_cs:
+            colpart = self._scratch("colpart", self._max_colpart, torch.float32)
+            assert (mpad // 64) * n <= colpart.numel(), what
+        if need_dx or need_dw or fuse_cs:
+            # one pass over d(output): row-major planes (data gradient), transposed planes (weight gradient), column sums
+            ops.append((lib.wd_dout_prep, (dout.data_ptr(), ldd, M, n, npad, mpad, _ptr(dpl[0]) if need_dx else None,
+                                           (_ptr(dpl[1]) if lo_ok else None) if need_dx else None,
+                                           _ptr(doutT[0]) if need_dw else None, _ptr(doutT[1]) if need_dw else None,
+                                           _ptr(colpart)), what + ":prep(dout)"))
         for si, s in enumerate(segs):
             c, ntaps = s["c"], s["ntaps"]
             planes = s["planes"]
@@ -286,14 +291,26 @@ class TrainEngine(UNetEngine):
         if film_off is not None:
             # per-sample column sums are the FiLM gradient; summing those over the batch is the bias gradient
             B = M // hw_out
-            self._colsum(ops, what + ":dfilm", dout.data_ptr(), ldd, M, n, hw_out,
-                         self._dfilm.data_ptr() + 4 * film_off, self.film_total, 0)
+            if fuse_cs:
+                ops.append((lib.wd_colsum_finish, (colpart.data_ptr(), hw_out // 64, n, B, self._dfilm.data_ptr() + 4 * film_off,
+                                                   self.film_total, 0, 1.0), what + ":dfilm"))
+            else:
+                self._colsum(ops, what + ":dfilm", dout.data_ptr(), ldd, M, n, hw_out,
+                             self._dfilm.data_ptr() + 4 * film_off, self.film_total, 0)
             for b in bias:
-                self._colsum(ops, what + ":dbias", self._dfilm.data_ptr() + 4 * film_off, self.film_total, B, n, B,
-                             b.data_ptr(), n, self._pacc(b))
+                if fuse_cs:
+                    ops.append((lib.wd_colsum_finish, (colpart.data_ptr(), mpad // 64, n, 1, b.data_ptr(), n, self._pacc(b), 1.0),
+                                what + ":dbias"))
+                else:
+                    self._colsum(ops, what + ":dbias", self._dfilm.data_ptr() + 4 * film_off, self.film_total, B, n, B,
+                                 b.data_ptr(), n, self._pacc(b))
         else:
             for b in bias:
-                self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
+                if fuse_cs:
+                    ops.append((lib.wd_colsum_finish, (colpart.data_ptr(), mpad // 64, n, 1, b.data_ptr(), n, self._pacc(b), 1.0),
+                                what + ":dbias"))
+                else:
+                    self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
 
     def _gn_bwd(self, P, what, srcs: List[TAct], gn: torch.nn.GroupNorm, eps, silu, dz: torch.Tensor):
         ops = P.bwd
@@ -664,6 +681,8 @@ class TrainEngine(UNetEngine):
         self._max_attn_scr = scr
         if scr:
             self._scratch("attn_bwd", scr, torch.float32)
+        self._max_colpart = (mpad // 64) * nmax
+        self._scratch("colpart", self._max_colpart, torch.float32)
         self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)
         self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)
         self._scratch("xT", 2 * self._max_xT, torch.bfloat16)
