@@ -201,17 +201,20 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ x
 }
 __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ part, int nblk, int c, int nseg,
                                                      float* __restrict__ out, int out_ld, int accumulate, float scale) {
-    // grid (ceil(c / 64), nseg); thread = (column, lane of 4 over the partial rows)
-    __shared__ double red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl, s = blockIdx.y;
+    // grid (ceil(c / 16), nseg); thread = (row lane rl of 16, column cl of 16): 64-byte coalesced reads, fixed-order sums
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl, s = blockIdx.y;
     double acc = 0.0;
     if (col < c)
-        for (int k = rl; k < nblk; k += 4) acc += (double)part[((long)s * nblk + k) * c + col];
+        for (int k = rl; k < nblk; k += 16) acc += (double)part[((long)s * nblk + k) * c + col];
     red[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && col < c) {
-        const float v = (float)((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * scale;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        const float v = (float)t * scale;
         float* o = out + (long)s * out_ld + col;
         *o = accumulate ? *o + v : v;
     }
@@ -549,16 +552,26 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(const float* __rest
         float ak[NKB], av[NKB];
 #pragma unroll
         for (int j = 0; j < NKB; ++j) ak[j] = av[j] = 0.f;
-        for (int t = 0; t < ntok; ++t) {
-            const float qv = q[(row0 + t) * ldq + col], gv = dout[(row0 + t) * ldo + col];
-            const float* cds = s_ds + (t * heads + hh) * NKB;
-            const float* cp = s_p + (t * heads + hh) * NKB;
+        for (int t0 = 0; t0 < ntok; t0 += 8) {  // eight tokens per round: their loads are in flight together
+            float qv[8], gv[8];
 #pragma unroll
-            for (int j = 0; j < NKB; ++j)
-                if (j < nk) {
-                    ak[j] += cds[j] * qv;
-                    av[j] += cp[j] * gv;
-                }
+            for (int u = 0; u < 8; ++u) {
+                const bool okt = t0 + u < ntok;
+                qv[u] = okt ? q[(row0 + t0 + u) * ldq + col] : 0.f;
+                gv[u] = okt ? dout[(row0 + t0 + u) * ldo + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u < ntok ? t0 + u : 0;  // (padding tokens multiply by 0)
+                const float* cds = s_ds + (t * heads + hh) * NKB;
+                const float* cp = s_p + (t * heads + hh) * NKB;
+#pragma unroll
+                for (int j = 0; j < NKB; ++j)
+                    if (j < nk) {
+                        ak[j] += cds[j] * qv[u];
+                        av[j] += cp[j] * gv[u];
+                    }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NKB; ++j)
@@ -804,7 +817,7 @@ extern "C" int wd_colsum(const float* x, int ld, int rows, int c, int seg, float
     WdLaunchScope scope(WD_CLS_OTHER, st);
     const int vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     hipLaunchKernelGGL(colsum_stage1, dim3(nblk, nseg, (c + 255) / 256), dim3(256), 0, st, x, ld, rows, c, seg, scratch, vec);
-    hipLaunchKernelGGL(colsum_stage2, dim3((c + 63) / 64, nseg), dim3(256), 0, st, scratch, nblk, c, nseg, out, out_ld,
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 15) / 16, nseg), dim3(256), 0, st, scratch, nblk, c, nseg, out, out_ld,
                        accumulate, scale);
     return wd_check_launch();
 }
@@ -997,7 +1010,7 @@ extern "C" int wd_colsum_finish(const float* part, int nblk, int c, int nseg, fl
     if (!part || !out || nblk <= 0 || c <= 0 || nseg <= 0) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
-    hipLaunchKernelGGL(colsum_stage2, dim3((c + 63) / 64, nseg), dim3(256), 0, st, part, nblk, c, nseg, out, out_ld, accumulate,
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 15) / 16, nseg), dim3(256), 0, st, part, nblk, c, nseg, out, out_ld, accumulate,
                        scale);
     return wd_check_launch();
 }
