@@ -157,6 +157,14 @@ int wd_emb_combine(const float* time, const float* label, const int64_t* y, int 
                    wd_bf16* out_lo, int out_ld, void* stream);
 int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, float* out, void* stream);
 
+/* Two chained folded cross-attentions in one launch (attn1 then attn2 of a base-model BasicTransformerBlock, unet.py:337-345;
+ * both read LayerNorm parameters of their own, here norm2 twice): out = B(A(x)) with A/B = x + bias + softmax(LN(x).Mq^T).Mo,
+ * optionally followed by the next LayerNorm as operand planes.  MFMA form only (planes from wd_xattn_fold). */
+int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, float eps, int heads, int L, const float* gamma_a,
+                  const float* beta_a, const wd_bf16* mq_pl_a, const wd_bf16* mot_pl_a, const float* bias_a, const float* gamma_b,
+                  const float* beta_b, const wd_bf16* mq_pl_b, const wd_bf16* mot_pl_b, const float* bias_b, float* out, int out_ld,
+                  const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, void* stream);
+
 /* nn.Embedding lookup + positional encoding (CharacterEncoder, unet.py:860-872; PE skipped when pe == NULL,
  * unetPhosc.py:726-729): planes[r][:] = table[ids[r]][:] + pe[r % seq_len][:]. ids are int64 or int32. */
 int wd_embed_tokens(const void* ids, int ids_are_i64, int rows, int seq_len, const float* table, int vocab, int c,

@@ -519,3 +519,43 @@ def test_folded_cross_attention(B, hw, c, heads, L):
         torch.cuda.synchronize()
         assert max_rel(out.cpu(), ref) < 2e-5 and torch.equal(out, out2)
         assert max_rel(unplanes(pl).cpu(), ref_n) < 3e-5
+
+
+def test_folded_cross_attention_pair():
+    """wd_xattn_pair == two wd_xattn_fused launches chained (attn1 -> attn2 -> norm3 planes), bit for bit."""
+    lib = N.lib()
+    B, hw, c, heads, L = 3, 100, 320, 4, 10
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(B * hw, c, generator=g) * 1.5).to(DEV)
+    lay = []
+    for _ in range(2):
+        mq_pl = (torch.randn(B, 2, 64, c, generator=g) * 0.05).to(torch.bfloat16)
+        mq_pl[:, :, heads * L:] = 0
+        mot_pl = (torch.randn(B, 2, c, 64, generator=g) * 0.05).to(torch.bfloat16)
+        mot_pl[:, :, :, heads * L:] = 0
+        lay.append(dict(ga=(torch.randn(c, generator=g) * 0.2 + 1).to(DEV), be=(torch.randn(c, generator=g) * 0.2).to(DEV),
+                        mq=mq_pl.to(DEV), mo=mot_pl.to(DEV), bi=(torch.randn(c, generator=g) * 0.1).to(DEV)))
+    ga3, be3 = (torch.randn(c, generator=g) * 0.2 + 1).to(DEV), (torch.randn(c, generator=g) * 0.2).to(DEV)
+    dummy = torch.zeros(B, heads * L, c, device=DEV)  # fp32 matrices: unused by the MFMA form
+
+    def single(xin, ly, nxt):
+        out = torch.zeros(B * hw, c, device=DEV)
+        pl = torch.zeros(2, B * hw, c, dtype=torch.bfloat16, device=DEV)
+        N.check(lib.wd_xattn_fused(xin.data_ptr(), c, B, hw, c, ly["ga"].data_ptr(), ly["be"].data_ptr(), 1e-5, dummy.data_ptr(),
+                                   dummy.data_ptr(), heads, L, ly["bi"].data_ptr(), out.data_ptr(), c,
+                                   ga3.data_ptr() if nxt else None, be3.data_ptr() if nxt else None, 1e-5,
+                                   pl[0].data_ptr() if nxt else None, pl[1].data_ptr() if nxt else None, c, ly["mq"].data_ptr(),
+                                   ly["mo"].data_ptr(), _st()), "fused")
+        return out, pl
+
+    t1, _ = single(x, lay[0], False)
+    t2, pl2 = single(t1, lay[1], True)
+    out = torch.zeros(B * hw, c, device=DEV)
+    pl = torch.zeros(2, B * hw, c, dtype=torch.bfloat16, device=DEV)
+    a, b = lay
+    N.check(lib.wd_xattn_pair(x.data_ptr(), c, B, hw, c, 1e-5, heads, L, a["ga"].data_ptr(), a["be"].data_ptr(), a["mq"].data_ptr(),
+                              a["mo"].data_ptr(), a["bi"].data_ptr(), b["ga"].data_ptr(), b["be"].data_ptr(), b["mq"].data_ptr(),
+                              b["mo"].data_ptr(), b["bi"].data_ptr(), out.data_ptr(), c, ga3.data_ptr(), be3.data_ptr(), 1e-5,
+                              pl[0].data_ptr(), pl[1].data_ptr(), c, _st()), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(out, t2) and torch.equal(pl, pl2)

@@ -260,12 +260,20 @@ int launch_fused(const float* x, int ld, int batch, int hw, const float* gamma, 
 typedef __attribute__((ext_vector_type(8))) __bf16 xa_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float xa_f32x16;
 
-template <int NI, int NW>  // c = NI * 32 (NI even); NW waves = 16 * NW tokens per workgroup
-__global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, const wd_bf16* __restrict__ mq_pl,
-                                                         const wd_bf16* __restrict__ mot_pl, int heads, int L,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int out_ld,
+struct XaLayer {  // one folded cross-attention: its LayerNorm, the folded matrices of this batch, the to_out bias
+    const float* gamma;
+    const float* beta;
+    const wd_bf16* mq_pl;
+    const wd_bf16* mot_pl;
+    const float* bias;
+};
+
+// NP = 2 chains the two cross-attentions of a base-model transformer block (both token-local): the intermediate token
+// stream never leaves the registers.
+template <int NI, int NW, int NP>  // c = NI * 32 (NI even); NW waves = 16 * NW tokens per workgroup
+__global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw, const XaLayer la,
+                                                         const XaLayer lb, float eps, int heads, int L,
+                                                         float* __restrict__ out, int out_ld,
                                                          const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                          float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
                                                          int n_ld) {
@@ -299,6 +307,15 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
             if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
         }
     const int rt = wave % RTN, cg = wave / RTN;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+    const XaLayer& ly = ps == 0 ? la : lb;
+    const float* __restrict__ gamma = ly.gamma;
+    const float* __restrict__ beta = ly.beta;
+    const wd_bf16* __restrict__ mq_pl = ly.mq_pl;
+    const wd_bf16* __restrict__ mot_pl = ly.mot_pl;
+    const float* __restrict__ bias = ly.bias;
+    const bool last = ps == NP - 1;
     constexpr int CH = 5;  // k-steps per prefetched chunk of the global operand
     static_assert(KSB % CH == 0 || KSB < CH, "chunking");
     constexpr int NCH = KSB >= CH ? KSB / CH : 1, CHN = KSB >= CH ? CH : KSB;
@@ -312,7 +329,8 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
             bl[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + i * 16);
         }
     }
-    for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
+    if (ps == 0)
+        for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
     // ---- LayerNorm -> split planes in LDS
     {
         float4 ga[FI], be[FI];
@@ -451,10 +469,10 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
                 const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + n);
                 xr[k][i] = make_float4(at.x + bi[i].x + xr[k][i].x, at.y + bi[i].y + xr[k][i].y, at.z + bi[i].z + xr[k][i].z,
                                        at.w + bi[i].w + xr[k][i].w);
-                if (ok) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
+                if (ok && last) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
                 s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
             }
-            if (n_hi) {
+            if (n_hi && last) {
                 const float mean = wd_row16_sum(s) / (float)C;
                 float q = 0.f;
 #pragma unroll
@@ -481,25 +499,27 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
             }
         }
     }
+    if (!last) __syncthreads();  // the output image is consumed before the next attention overwrites the token planes
+    }
 }
 
-template <int NI, int NW>
-int launch_mfma(const float* x, int ld, int batch, int hw, const float* gamma, const float* beta, float eps, const wd_bf16* mq_pl,
-                const wd_bf16* mot_pl, int heads, int L, const float* bias, float* out, int out_ld, const float* gamma2,
-                const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, hipStream_t st) {
+template <int NI, int NW, int NP>
+int launch_mfma(const float* x, int ld, int batch, int hw, const XaLayer& la, const XaLayer& lb, float eps, int heads, int L,
+                float* out, int out_ld, const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo,
+                int n_ld, hipStream_t st) {
     constexpr int C = NI * 32, XTM = 16 * NW;
     constexpr size_t xb = (size_t)2 * XTM * (C + 8) * 2 > (size_t)XTM * (C + 4) * 4 ? (size_t)2 * XTM * (C + 8) * 2 : (size_t)XTM * (C + 4) * 4;
     constexpr size_t smem = xb + (size_t)XTM * (XHJ + 1) * 4 + (size_t)2 * XTM * (XHJ + 8) * 2;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI, NW, NP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return WD_ELAUNCH;
         attr = true;
     }
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW>), dim3((hw + XTM - 1) / XTM, batch), dim3(64 * NW), smem, st, x, ld, hw, gamma, beta, eps,
-                       mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
+    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW, NP>), dim3((hw + XTM - 1) / XTM, batch), dim3(64 * NW), smem, st, x, ld, hw, la, lb,
+                       eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
     return wd_check_launch();
 }
 
@@ -529,11 +549,10 @@ extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, 
     if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mq_pl && mot_pl && !getenv("WDIFF_XATTN_VALU")) {
+        const XaLayer la = {gamma, beta, mq_pl, mot_pl, bias};
         if (c == 320)
-            return launch_mfma<10, 2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2,
-                                   eps2, n_hi, n_lo, n_ld, st);
-        return launch_mfma<2, 2>(x, ld, batch, hw, gamma, beta, eps, mq_pl, mot_pl, heads, L, bias, out, out_ld, gamma2, beta2, eps2,
-                              n_hi, n_lo, n_ld, st);
+            return launch_mfma<10, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+        return launch_mfma<2, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
     }
     const int nh = (heads * L + 7) / 8;
 #define WD_XA(NI_, NH_)                                                                                                     \
@@ -558,4 +577,20 @@ extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, 
     }
 #undef WD_XA
     return WD_EINVAL;
+}
+
+extern "C" int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, float eps, int heads, int L, const float* gamma_a,
+                             const float* beta_a, const wd_bf16* mq_pl_a, const wd_bf16* mot_pl_a, const float* bias_a,
+                             const float* gamma_b, const float* beta_b, const wd_bf16* mq_pl_b, const wd_bf16* mot_pl_b,
+                             const float* bias_b, float* out, int out_ld, const float* gamma2, const float* beta2, float eps2,
+                             wd_bf16* n_hi, wd_bf16* n_lo, int n_ld, void* stream) {
+    if (!x || !out || !gamma_a || !beta_a || !mq_pl_a || !mot_pl_a || !bias_a || !gamma_b || !beta_b || !mq_pl_b || !mot_pl_b ||
+        !bias_b || batch <= 0 || hw <= 0)
+        return WD_EINVAL;
+    if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const XaLayer la = {gamma_a, beta_a, mq_pl_a, mot_pl_a, bias_a}, lb = {gamma_b, beta_b, mq_pl_b, mot_pl_b, bias_b};
+    if (c == 320)
+        return launch_mfma<10, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+    return launch_mfma<2, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
 }

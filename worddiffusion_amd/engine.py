@@ -265,6 +265,7 @@ class UNetEngine:
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
+        self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
@@ -648,9 +649,8 @@ class UNetEngine:
         xpl = None
         fuse = self.fuse_xattn and bool(self.lib.wd_xattn_supported(inner, heads, L))
 
-        def folded(tag, p, x_in, x_out, ln_name, next_ln=None):
-            """x_out = x_in + to_out(attention(to_q(LN(x_in)), K, V)) in one launch; K/V/to_q/to_out folded per sample in the
-            conditioning phase (csrc/wd_xattn.hip).  next_ln: also emit the following LayerNorm as operand planes."""
+        def fold(tag, p):
+            """K/V/to_q/to_out of one cross-attention folded per sample in the conditioning phase (csrc/wd_xattn.hip)."""
             ko = self.kv_off[f"{p}.{tag}"]
             mq = self._f32(P, B, heads * L, inner)
             mo = self._f32(P, B, heads * L, inner)
@@ -662,6 +662,12 @@ class UNetEngine:
                             heads, L, d, float(d ** -0.5), self._w[f"{p}.{tag}.q.f32"].data_ptr(),
                             self._w[f"{p}.{tag}.o.f32"].data_ptr(), inner, mq.data_ptr(), mo.data_ptr(), mq_pl.data_ptr(),
                             mot_pl.data_ptr()), f"{p}.{tag}:fold"))
+            return mq, mo, mq_pl, mot_pl
+
+        def folded(tag, p, x_in, x_out, ln_name, next_ln=None):
+            """x_out = x_in + to_out(attention(to_q(LN(x_in)), K, V)) in one launch.  next_ln: also emit the following
+            LayerNorm as operand planes."""
+            mq, mo, mq_pl, mot_pl = fold(tag, p)
             npl = self._planes(P, M, inner) if next_ln else None
             ops.append((self.lib.wd_xattn_fused,
                         (x_in.data_ptr(), inner, B, hw, inner, self._w[f"{p}.{ln_name}.g"].data_ptr(),
@@ -674,13 +680,32 @@ class UNetEngine:
                         f"{p}.{tag}:folded"))
             return npl
 
+        def folded_pair(p, x_in, x_out):
+            """Both cross-attentions of a base-model block (each behind norm2, unet.py:337-345) and norm3 in one launch."""
+            _, _, qa, oa = fold("a1", p)
+            _, _, qb, ob = fold("a2", p)
+            npl = self._planes(P, M, inner)
+            g2, b2 = self._w[f"{p}.norm2.g"].data_ptr(), self._w[f"{p}.norm2.b"].data_ptr()
+            ops.append((self.lib.wd_xattn_pair,
+                        (x_in.data_ptr(), inner, B, hw, inner, 1e-5, heads, L, g2, b2, qa.data_ptr(), oa.data_ptr(),
+                         self._w[f"{p}.a1.o.b"].data_ptr(), g2, b2, qb.data_ptr(), ob.data_ptr(),
+                         self._w[f"{p}.a2.o.b"].data_ptr(), x_out.data_ptr(), inner, self._w[f"{p}.norm3.g"].data_ptr(),
+                         self._w[f"{p}.norm3.b"].data_ptr(), 1e-5, npl[0].data_ptr(),
+                         npl[1].data_ptr() if self.npass == 3 else None, inner), f"{p}.a1+a2:folded"))
+            return npl
+
         for di, tb in enumerate(mod.transformer_blocks):
             p = f"{name}.tb{di}"
             scale = d ** -0.5
             n3 = None
             # ---- attn1
-            tok1 = self._f32(P, M, inner)
-            if self.variant == "phosc":
+            if fuse and self.variant != "phosc" and self.fuse_xattn_pair:
+                tok2 = self._f32(P, M, inner)
+                n3 = folded_pair(p, tok, tok2)
+            tok1 = self._f32(P, M, inner) if n3 is None else None
+            if n3 is not None:
+                pass
+            elif self.variant == "phosc":
                 n1 = self._ln(P, ops, p + ".norm1", tok, M, inner, p + ".norm1")
                 qkv = self._f32(P, M, 3 * inner)
                 self._gemm(ops, p + ".a1.qkv", [self._src(n1, inner)], p + ".a1.qkv.w", M, hw, out_f32=qkv,
@@ -703,10 +728,13 @@ class UNetEngine:
                 self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
                            resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
             # ---- attn2 (cross)
-            tok2 = self._f32(P, M, inner)
-            if fuse:
+            if n3 is not None:
+                pass
+            elif fuse:
+                tok2 = self._f32(P, M, inner)
                 n3 = folded("a2", p, tok1, tok2, "norm2", next_ln="norm3")
             else:
+                tok2 = self._f32(P, M, inner)
                 n2 = self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
                 q2 = self._f32(P, M, inner)
                 self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
