@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--slab", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--ksplit", type=int, default=1)
+    ap.add_argument("--stamps", type=int, default=0, help="1: per-stage cycle stamps of workgroup 0 (s_memtime)")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
                     "2: same, then read the weights once (emulates a prefetch) before the launch")
     a = ap.parse_args()
@@ -77,6 +78,23 @@ def main():
         ws = torch.empty(8 * m * cout if a.ksplit != 1 and m * cout * 8 < 2 ** 28 else 1, device=DEV)
         if a.ksplit != 1:
             g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
+        if a.stamps:
+            nk = ktot // 64
+            sb = torch.zeros(8 * nk * 4, dtype=torch.int64, device=DEV)
+            g.ws, g.ws_floats, g.dbg = sb.data_ptr(), 0, a.dbg | 0x100
+            N.check(lib.wd_gemm(C.byref(g), st), name)
+            torch.cuda.synchronize()
+            v = sb.cpu().view(8, nk, 4)
+            for wv in (0, 4):
+                w = v[wv]
+                wait = (w[:, 1] - w[:, 0]).float()       # barrier + vmcnt wait
+                rd = (w[:, 2] - w[:, 1]).float()         # address prep + ds_read of the fragments (until they landed)
+                mf = (w[:, 3] - w[:, 2]).float()         # MFMA groups with the DMA issue interleaved
+                tot = (w[1:, 0] - w[:-1, 0]).float()
+                print(f"{name} wave {wv}: per stage (s_memtime ticks, 100 MHz?) wait {wait[2:-1].mean():.1f}  frag-read {rd[2:-1].mean():.1f}  "
+                      f"mfma+dma {mf[2:-1].mean():.1f}  stage {tot[2:-1].mean():.1f}   whole loop {int(w[-1, 3] - w[0, 0])}")
+            g.dbg = a.dbg
+            g.ws, g.ws_floats = None, 0
         if a.slab:
             g.w_layout, g.slab_rows = 1, slab_span(tab_np, hw, hw, m)
         if kind == "geglu" and not g.tile:

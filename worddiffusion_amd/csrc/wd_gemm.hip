@@ -18,6 +18,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
@@ -211,6 +212,31 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
     }
 }
 
+// after the fp32 image of the tile is complete: split-K partial store, or the fused epilogue
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void wd_epilogue_tail(const wd_gemm_args& a, float* ep, const int m0, const int n0, const int tid,
+                                                 const int sidx) {
+    constexpr int LDE = BN + 4;
+    if (a.ksplit > 1) {  // raw partial sums of this K slice -> ws[sidx][m][n]; wd_gemm_reduce applies the epilogue
+        float* ws = a.ws + (long)sidx * a.m * a.n;
+        const bool v4 = (a.n & 3) == 0;
+        for (int i = tid; i < BM * (BN / 4); i += NT) {
+            const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + c;
+            if (m >= a.m || n >= a.n) continue;
+            const float4 v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+            if (v4) {
+                *reinterpret_cast<float4*>(ws + (long)m * a.n + n) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < 4 && n + j < a.n; ++j) ws[(long)m * a.n + n + j] = e[j];
+            }
+        }
+        return;
+    }
+    wd_epilogue_from_image<BM, BN, NT>(a, ep, m0, n0, tid);
+}
+
 template <int BM, int BN, int TN, int NT>
 __device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32x16 (&acc)[TN], char* smem, const int m0,
                                                 const int n0, const int wm, const int wn, const int wcols, const int kh,
@@ -233,24 +259,7 @@ __device__ __forceinline__ void wd_epilogue_lds(const wd_gemm_args& a, const f32
         }
         __syncthreads();
     }
-    if (a.ksplit > 1) {  // raw partial sums of this K slice -> ws[sidx][m][n]; wd_gemm_reduce applies the epilogue
-        float* ws = a.ws + (long)sidx * a.m * a.n;
-        const bool v4 = (a.n & 3) == 0;
-        for (int i = tid; i < BM * (BN / 4); i += NT) {
-            const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
-            const int m = m0 + row, n = n0 + c;
-            if (m >= a.m || n >= a.n) continue;
-            const float4 v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
-            if (v4) {
-                *reinterpret_cast<float4*>(ws + (long)m * a.n + n) = v;
-            } else {
-                const float e[4] = {v.x, v.y, v.z, v.w};
-                for (int j = 0; j < 4 && n + j < a.n; ++j) ws[(long)m * a.n + n + j] = e[j];
-            }
-        }
-        return;
-    }
-    wd_epilogue_from_image<BM, BN, NT>(a, ep, m0, n0, tid);
+    wd_epilogue_tail<BM, BN, NT>(a, ep, m0, n0, tid, sidx);
 }
 
 template <int BM, int BN, int NPASS>
@@ -454,8 +463,12 @@ __device__ __forceinline__ int lds_off2(int row, int ch) { return row * 128 + ((
 //         previous stage), so that on every SIMD one wave is in its LDS-read phase while the other is in its MFMA phase:
 //         the LDS port (192 KB of fragment reads + 74 KB of DMA writes per stage) and the MFMA pipe work concurrently
 //         instead of alternately.
-template <int BM, int BN, int NPASS, int KS, bool PP = false>
+// M16 (128 x 160 tile, KS = 2): v_mfma_f32_16x16x32_bf16 with a 64 x 80 wave tile (4 x 5 tiles of 16 x 16) instead of
+//         32x32x16 with 32 x 160: the same accumulator registers and MFMA cycles, but 18 instead of 24 ds_read_b128 of
+//         fragments per wave and stage - the loop is LDS-port bound (per-stage stamps: tools/gemm_bench.py --stamps).
+template <int BM, int BN, int NPASS, int KS, bool PP = false, bool M16 = false>
 __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+    static_assert(!M16 || (BM == 128 && BN == 160 && KS == 2 && !PP), "M16 is the 128x160 KS=2 kernel");
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int NW = 4 * KS;
     constexpr int WM = BM / 32, WN = 4 / WM;
@@ -628,6 +641,13 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 acc16[M16 ? 4 : 1][M16 ? 5 : 1];
+#pragma unroll
+    for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+        for (int t = 0; t < (M16 ? 5 : 1); ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][t][r] = 0.0f;
 
     const int nk = k_end - k_begin;
     if (nk > 0) {
@@ -672,28 +692,10 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if (PP && KS == 2 && kh == 1) {
-        // late group (its own loop, so that the fragments carried across the barrier do not constrain the early group's
-        // register allocation): multiply the fragments of the previous stage while the early group reads this one; only
-        // then (fragments dead) compute and issue its share of the next stage's DMA, then read this stage
-        for (int kit = 0; kit < nk; ++kit) {
-            __syncthreads();
-            const bool more = kit + 1 < nk;
-            const char* base = smem + (kit & 1) * STAGE;
-            char* nbase = smem + ((kit + 1) & 1) * STAGE;
-            if (kit > 0) mfma_stage(false, nbase);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                prep(k_begin + kit + 1);
-                advance();
-#pragma unroll
-                for (int sl = 0; sl < NSLOT; ++sl) fire(sl, nbase);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(base);
-        }
-        if (nk > 0) mfma_stage(false, smem);
-    } else {
+    if constexpr (M16) {
+        // wave = (K-half kh, row half wq >> 1, column half wq & 1): 64 rows x 80 columns, one 32-deep k-step per stage
+        const int l15 = lane & 15, lq = lane >> 4;
+        const int r0w = (wq >> 1) * 64, c0w = (wq & 1) * 80;
         for (int kit = 0; kit < nk; ++kit) {
             __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
             const bool more = kit + 1 < nk;
@@ -703,9 +705,113 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 prep(k_begin + kit + 1);
                 advance();
             }
+            bf16x8 xa[4][NPL], xb[5][NPL];
+            const int ch = kh * 4 + lq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ao = lds_off2(r0w + i * 16 + l15, ch);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) xa[i][p] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + ao);
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int bo = NPL * A_PL + lds_off2(c0w + t * 16 + l15, ch);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) xb[t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    if (NPL == 2) {
+                        acc16[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], xb[t][0], acc16[i][t], 0, 0, 0);
+                        acc16[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][NPL - 1], acc16[i][t], 0, 0, 0);
+                    }
+                    acc16[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][0], acc16[i][t], 0, 0, 0);
+                }
+                if (more) {  // this wave's DMA pieces of the next stage, spread over the four row groups
+#pragma unroll
+                    for (int sl = i * NSLOT / 4; sl < (i + 1) * NSLOT / 4; ++sl) fire(sl, nbase);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- partial tiles -> fp32 LDS image (the two K-halves summed in a fixed order), then the shared epilogue
+        constexpr int LDE = BN + 4;
+        float* ep = reinterpret_cast<float*>(smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int hh = 0; hh < 2; ++hh) {
+            if (kh == hh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 5; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* pe = ep + (r0w + i * 16 + 4 * lq + r) * LDE + c0w + t * 16 + l15;
+                            *pe = (hh == 0) ? acc16[i][t][r] : *pe + acc16[i][t][r];
+                        }
+            }
+            __syncthreads();
+        }
+        wd_epilogue_tail<BM, BN, 256 * KS>(a, ep, m0, n0, tid, sidx);
+        return;
+    }
+    if (PP && KS == 2 && kh == 1) {
+        // late group (its own loop, so that the fragments carried across the barrier do not constrain the early group's
+        // register allocation): multiply the fragments of the previous stage while the early group reads this one; only
+        // then (fragments dead) compute and issue its share of the next stage's DMA, then read this stage
+        const bool stamp_l = (a.dbg & 0x100) && blockIdx.x == 0 && lane == 0 && a.ws;
+        unsigned long long* sbuf_l = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
+        for (int kit = 0; kit < nk; ++kit) {
+            if (stamp_l) sbuf_l[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            if (stamp_l) sbuf_l[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
+            const bool more = kit + 1 < nk;
+            const char* base = smem + (kit & 1) * STAGE;
+            char* nbase = smem + ((kit + 1) & 1) * STAGE;
+            if (kit > 0) mfma_stage(false, nbase);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamp_l) sbuf_l[kit * 4 + 2] = __builtin_amdgcn_s_memtime();   // (late group: [1..2] = MFMA, [2..3] = DMA + reads)
+            if (more) {
+                prep(k_begin + kit + 1);
+                advance();
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) fire(sl, nbase);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(base);
+            if (stamp_l) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sbuf_l[kit * 4 + 3] = __builtin_amdgcn_s_memtime();
+            }
+        }
+        if (nk > 0) mfma_stage(false, smem);
+    } else {
+        // (a.dbg & 0x100: per-stage cycle stamps of workgroup 0 into a.ws as u64 [wave][stage][4] - tools/gemm_bench.py --stamps)
+        const bool stamp = (a.dbg & 0x100) && blockIdx.x == 0 && lane == 0 && a.ws;
+        unsigned long long* sbuf = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
+        for (int kit = 0; kit < nk; ++kit) {
+            if (stamp) sbuf[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
+            __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+            if (stamp) sbuf[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
+            const bool more = kit + 1 < nk;
+            const char* base = smem + (kit & 1) * STAGE;
+            char* nbase = smem + ((kit + 1) & 1) * STAGE;
+            if (more) {
+                prep(k_begin + kit + 1);
+                advance();
+            }
             read_frags(base);
             __builtin_amdgcn_sched_barrier(0);
+            if (stamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sbuf[kit * 4 + 2] = __builtin_amdgcn_s_memtime();
+            }
             mfma_stage(more, nbase);
+            if (stamp) sbuf[kit * 4 + 3] = __builtin_amdgcn_s_memtime();
         }
     }
 
@@ -1084,7 +1190,7 @@ int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
-template <int BM, int BN, int NPASS, int KS, bool PP = false>
+template <int BM, int BN, int NPASS, int KS, bool PP = false, bool M16 = false>
 int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int loop_smem = 2 * NPL * (BM + BN) * 128 + 9 * BM * 4;
@@ -1092,7 +1198,7 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS, KS, PP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm2_kernel<BM, BN, NPASS, KS, PP, M16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return WD_ELAUNCH;
         attr_done = true;
@@ -1101,7 +1207,7 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     {
         WdLaunchScope scope((BM == 128 && BN == 160) ? WD_CLS_GEMM : WD_CLS_GEMM_OTHER, st,
                             2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-        hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS, PP>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
+        hipLaunchKernelGGL((wd_gemm2_kernel<BM, BN, NPASS, KS, PP, M16>), dim3(nbn * nbm * a.ksplit), dim3(256 * KS), smem, st, a,
                            nbn, nbm);
     }
     if (a.ksplit > 1) {
@@ -1201,6 +1307,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
     static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
     const int ks = ks_env == 1 ? 1 : 2;
+    static const bool m16 = getenv("WDIFF_GEMM_M16") ? atoi(getenv("WDIFF_GEMM_M16")) != 0 : true;
     static const bool pp = getenv("WDIFF_GEMM_PP") ? atoi(getenv("WDIFF_GEMM_PP")) != 0 : false;  // measured: no gain
 #define WD_DISPATCH(BM_, BN_)                                                                      \
     if (v2ok && ks == 2 && pp) return a.npass == 3 ? launch2<BM_, BN_, 3, 2, true>(a, st) : launch2<BM_, BN_, 1, 2, true>(a, st); \
@@ -1210,7 +1317,10 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     return a.npass == 3 ? launch<BM_, BN_, 3>(a, st) : launch<BM_, BN_, 1>(a, st)
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);
-        case 128160: WD_DISPATCH(128, 160);
+        case 128160:
+            if (v2ok && ks == 2 && m16)
+                return a.npass == 3 ? launch2<128, 160, 3, 2, false, true>(a, st) : launch2<128, 160, 1, 2, false, true>(a, st);
+            WD_DISPATCH(128, 160);
         case 128128: WD_DISPATCH(128, 128);
         case 64064: WD_DISPATCH(64, 64);
         default: return WD_EINVAL;
