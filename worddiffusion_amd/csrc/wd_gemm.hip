@@ -696,16 +696,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         // wave = (K-half kh, row half wq >> 1, column half wq & 1): 64 rows x 80 columns, one 32-deep k-step per stage
         const int l15 = lane & 15, lq = lane >> 4;
         const int r0w = (wq >> 1) * 64, c0w = (wq & 1) * 80;
-        for (int kit = 0; kit < nk; ++kit) {
-            __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
-            const bool more = kit + 1 < nk;
-            const char* base = smem + (kit & 1) * STAGE;
-            char* nbase = smem + ((kit + 1) & 1) * STAGE;
-            if (more) {
-                prep(k_begin + kit + 1);
-                advance();
-            }
-            bf16x8 xa[4][NPL], xb[5][NPL];
+        bf16x8 xa[4][NPL], xb[5][NPL];
+        auto read16 = [&](const char* base) {
             const int ch = kh * 4 + lq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -719,7 +711,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) xb[t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfma16 = [&](bool more, char* nbase) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -735,6 +728,41 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                     for (int sl = i * NSLOT / 4; sl < (i + 1) * NSLOT / 4; ++sl) fire(sl, nbase);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (a.dbg & 0x200 ? kh == 1 : false) {
+            // stagger (a.dbg & 0x200): the second K-half group multiplies one stage late, so its LDS reads fall under the
+            // first group's MFMAs and vice versa
+            for (int kit = 0; kit < nk; ++kit) {
+                __syncthreads();
+                const bool more = kit + 1 < nk;
+                const char* base = smem + (kit & 1) * STAGE;
+                char* nbase = smem + ((kit + 1) & 1) * STAGE;
+                if (kit > 0) mfma16(false, nbase);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    prep(k_begin + kit + 1);
+                    advance();
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) fire(sl, nbase);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read16(base);
+            }
+            if (nk > 0) mfma16(false, smem);
+        } else {
+            for (int kit = 0; kit < nk; ++kit) {
+                __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+                const bool more = kit + 1 < nk;
+                const char* base = smem + (kit & 1) * STAGE;
+                char* nbase = smem + ((kit + 1) & 1) * STAGE;
+                if (more) {
+                    prep(k_begin + kit + 1);
+                    advance();
+                }
+                read16(base);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(more, nbase);
             }
         }
         // ---- partial tiles -> fp32 LDS image (the two K-halves summed in a fixed order), then the shared epilogue
@@ -1307,6 +1335,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
     static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
     const int ks = ks_env == 1 ? 1 : 2;
+    static const int stagger_min = getenv("WDIFF_GEMM_STAGGER_MIN") ? atoi(getenv("WDIFF_GEMM_STAGGER_MIN")) : 16;
+    static const bool stagger = getenv("WDIFF_GEMM_STAGGER") ? atoi(getenv("WDIFF_GEMM_STAGGER")) != 0 : true;
     static const bool m16 = getenv("WDIFF_GEMM_M16") ? atoi(getenv("WDIFF_GEMM_M16")) != 0 : true;
     static const bool pp = getenv("WDIFF_GEMM_PP") ? atoi(getenv("WDIFF_GEMM_PP")) != 0 : false;  // measured: no gain
 #define WD_DISPATCH(BM_, BN_)                                                                      \
@@ -1318,6 +1348,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);
         case 128160:
+            // second K-half group runs one stage late (see the kernel); the extra drain phase only pays on long K loops
+            if (v2ok && ks == 2 && m16 && stagger && nk64 / a.ksplit >= stagger_min) a.dbg |= 0x200;
             if (v2ok && ks == 2 && m16)
                 return a.npass == 3 ? launch2<128, 160, 3, 2, false, true>(a, st) : launch2<128, 160, 1, 2, false, true>(a, st);
             WD_DISPATCH(128, 160);
