@@ -616,6 +616,32 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         if (pdst[sl] >= 0)
             __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pp[sl], (wd_lds_ptr)(sbase + pdst[sl]), 16, 0, 0);
     };
+    // address computation and issue in one go (no per-slot pointer array kept live)
+    auto prep_fire_all = [&](int kit, char* sbase) {
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < A_PIECES) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    const wd_bf16* src = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK2 : zline;
+                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_INS; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < B_PIECES) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    const wd_bf16* src = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK2 : zline;
+                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16,
+                                                     0, 0);
+                }
+            }
+        }
+    };
     auto advance = [&]() {
         ++kc;
         if (kc * BK2 == cur_c) {
@@ -730,29 +756,40 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        const bool stamp16 = (a.dbg & 0x100) && blockIdx.x == 0 && lane == 0 && a.ws;
+        unsigned long long* sb16 = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
         if (a.dbg & 0x200 ? kh == 1 : false) {
             // stagger (a.dbg & 0x200): the second K-half group multiplies one stage late, so its LDS reads fall under the
             // first group's MFMAs and vice versa
             for (int kit = 0; kit < nk; ++kit) {
+                if (stamp16) sb16[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
                 __syncthreads();
+                if (stamp16) sb16[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
                 const bool more = kit + 1 < nk;
                 const char* base = smem + (kit & 1) * STAGE;
                 char* nbase = smem + ((kit + 1) & 1) * STAGE;
-                if (kit > 0) mfma16(false, nbase);
-                __builtin_amdgcn_sched_barrier(0);
+                // the late group's DMA of the next stage goes out first (the buffer is free as of this barrier and the pieces
+                // then have the whole stage to land), then it multiplies the previous stage's fragments, then it reads
                 if (more) {
-                    prep(k_begin + kit + 1);
+                    prep_fire_all(k_begin + kit + 1, nbase);
                     advance();
-#pragma unroll
-                    for (int sl = 0; sl < NSLOT; ++sl) fire(sl, nbase);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (kit > 0) mfma16(false, nbase);
+                __builtin_amdgcn_sched_barrier(0);
+                if (stamp16) sb16[kit * 4 + 2] = __builtin_amdgcn_s_memtime();  // late group: [1..2] DMA + MFMA, [2..3] reads
                 read16(base);
+                if (stamp16) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    sb16[kit * 4 + 3] = __builtin_amdgcn_s_memtime();
+                }
             }
             if (nk > 0) mfma16(false, smem);
         } else {
             for (int kit = 0; kit < nk; ++kit) {
+                if (stamp16) sb16[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
                 __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+                if (stamp16) sb16[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
                 const bool more = kit + 1 < nk;
                 const char* base = smem + (kit & 1) * STAGE;
                 char* nbase = smem + ((kit + 1) & 1) * STAGE;
@@ -762,7 +799,12 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 }
                 read16(base);
                 __builtin_amdgcn_sched_barrier(0);
+                if (stamp16) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    sb16[kit * 4 + 2] = __builtin_amdgcn_s_memtime();
+                }
                 mfma16(more, nbase);
+                if (stamp16) sb16[kit * 4 + 3] = __builtin_amdgcn_s_memtime();
             }
         }
         // ---- partial tiles -> fp32 LDS image (the two K-halves summed in a fixed order), then the shared epilogue
