@@ -289,9 +289,9 @@ def main():
         try:  # HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/, per round)
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                               "r01_pmc_hbm_traffic.json")))
-            k = pmc["wd_gemm2_kernel<128, 160, 3, 2>"]
+            k = pmc["wd_gemm2_kernel<128, 160, 3, 2, false, true>"]
             traffic = (k["fetch_mb_corrected"] + k["write_mb"]) * 1e6
-            traffic_note = ("HBM bytes per launch of wd_gemm2_kernel<128,160,3,2>: %.1f MB fetched (FETCH_SIZE, gfx950 x2 "
+            traffic_note = ("HBM bytes per launch of wd_gemm2_kernel<128,160,3,2,M16> (its 256-workgroup launches): %.1f MB fetched (FETCH_SIZE, gfx950 x2 "
                             "correction) + %.1f MB written (WRITE_SIZE); separate rocprofv3 --pmc passes over this bench "
                             "command, profiles/r01_pmc_hbm_traffic.json" % (k["fetch_mb_corrected"], k["write_mb"]))
         except (OSError, KeyError, ValueError):

@@ -247,7 +247,9 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wd_bf16* sK = reinterpret_cast<wd_bf16*>(smem);   // [2 planes][FA_KB][KP]
     wd_bf16* sV = sK + 2 * FA_KB * KP;                // [2 planes][DVR][VP]
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_QB;
+    // grid (heads, batch, query tiles): the query tiles of one (sample, head) share K/V - consecutive workgroup ids are
+    // different (sample, head) pairs, so those tiles land on the same XCD (ids 8 apart... see launch) and hit its L2
+    const int b = blockIdx.y, h = blockIdx.x, q0 = blockIdx.z * FA_QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -404,7 +406,7 @@ static int launch_attn_mfma(const float* q, int ldq, const float* k, int ldk, co
     constexpr size_t smem = tiles > stage ? tiles : stage;
     static_assert(smem <= 64 * 1024, "attention tile does not fit the default dynamic LDS limit");
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT>), dim3((nq + FA_QB - 1) / FA_QB, heads, batch), dim3(256), smem, st, q, ldq, k,
+    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT>), dim3(heads, batch, (nq + FA_QB - 1) / FA_QB), dim3(256), smem, st, q, ldq, k,
                        ldk, v, ldv, heads, nq, nk, scale, out_f32, out_hi, out_lo, out_ld, out_rows, out_row0);
     return wd_check_launch();
 }

@@ -285,7 +285,9 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     constexpr size_t XBYTES = (size_t)2 * XT * XP * 2 > (size_t)XT * OP * 4 ? (size_t)2 * XT * XP * 2 : (size_t)XT * OP * 4;
     float* sS = reinterpret_cast<float*>(smem + XBYTES);                          // [XT][SP] scores
     wd_bf16* sP = reinterpret_cast<wd_bf16*>(smem + XBYTES + (size_t)XT * SP * 4);  // [2][XT][PP] probabilities (planes)
-    const int b = blockIdx.y, t0 = blockIdx.x * XT;
+    // grid (batch, token tiles): consecutive workgroup ids = consecutive samples, so the token tiles of one sample (which
+    // share its folded matrices) are dealt to the same XCD and find them in its L2
+    const int b = blockIdx.x, t0 = blockIdx.y * XT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int HJ = heads * L;
@@ -518,7 +520,7 @@ int launch_mfma(const float* x, int ld, int batch, int hw, const XaLayer& la, co
         attr = true;
     }
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW, NP>), dim3((hw + XTM - 1) / XTM, batch), dim3(64 * NW), smem, st, x, ld, hw, la, lb,
+    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW, NP>), dim3(batch, (hw + XTM - 1) / XTM), dim3(64 * NW), smem, st, x, ld, hw, la, lb,
                        eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
     return wd_check_launch();
 }
