@@ -38,7 +38,7 @@ SLAB = [False, True]
 
 
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1):
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0):
     """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
     slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
@@ -59,6 +59,8 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
             pytest.skip("slab kernel not applicable (span / tile)")
         wp = slab_order(wp, a_list[0][2], a_list[0][1], a_list[1][1] if len(a_list) > 1 else 0)
         args.w_layout, args.slab_rows = 1, span
+    if same_w:  # row-shared taps kernel for 3x3 / pad 1 / stride 1 (w_layout 2)
+        args.w_layout, args.slab_rows = 2, same_w
     keep.append(wp)
     args.w_hi, args.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
     n = w.shape[0] if n is None else n
@@ -559,3 +561,34 @@ def test_folded_cross_attention_pair():
                               pl[0].data_ptr(), pl[1].data_ptr(), c, _st()), "pair")
     torch.cuda.synchronize()
     assert torch.equal(out, t2) and torch.equal(pl, pl2)
+
+
+@pytest.mark.parametrize("B,h,w,cin,cout,skip,ksplit", [(3, 8, 32, 64, 160, 0, 1), (2, 8, 32, 128, 320, 64, 1), (3, 5, 7, 64, 96, 0, 1),
+                                                          (5, 4, 16, 64, 320, 128, 0), (2, 3, 200, 64, 64, 0, 1),
+                                                          (64, 8, 32, 320, 320, 0, 1)])
+def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit):
+    """wd_gemm with w_layout 2 (wd_conv3_kernel: the three taps of a kernel row share one A tile, 16x16x32 MFMA, stagger) vs
+    F.conv2d (+ 1x1 skip over a second source), incl. panels that straddle samples, narrow / wide images, split-K, and the
+    headline shape."""
+    g = torch.Generator().manual_seed(B * 100 + h * 10 + w + cin)
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    tab, _, _ = conv_gather_table(h, w, "same")
+    hw, m = h * w, B * h * w
+    tok = x.permute(0, 2, 3, 1).reshape(m, cin).contiguous()
+    a_list = [(planes_of(tok.to(DEV)), cin, 9, torch.from_numpy(tab).to(DEV), hw)]
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+    if skip:
+        x2 = torch.randn(B, skip, h, w, generator=g)
+        ws = torch.randn(cout, skip, generator=g) / skip ** 0.5
+        ref = ref + F.conv2d(x2.double(), ws.double()[:, :, None, None])
+        a_list.append((planes_of(x2.permute(0, 2, 3, 1).reshape(m, skip).contiguous().to(DEV)), skip, 1, None, 0))
+        wp = torch.cat([wp, ws], 1)
+    out, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), same_w=w, ksplit=ksplit)
+    got = out.cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    assert max_rel(got, ref) < 2e-5
+    # same result as the generic kernel up to summation order
+    out0, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), ksplit=ksplit)
+    assert max_rel(out.cpu(), out0.cpu()) < 5e-6

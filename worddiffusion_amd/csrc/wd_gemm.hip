@@ -763,6 +763,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
             // first group's MFMAs and vice versa
             for (int kit = 0; kit < nk; ++kit) {
                 if (stamp16) sb16[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (stamp16) sb16[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
                 const bool more = kit + 1 < nk;
@@ -788,7 +789,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         } else {
             for (int kit = 0; kit < nk; ++kit) {
                 if (stamp16) sb16[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
-                __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // step kit has landed, the other stage buffer is free
                 if (stamp16) sb16[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
                 const bool more = kit + 1 < nk;
                 const char* base = smem + (kit & 1) * STAGE;
@@ -837,6 +839,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         unsigned long long* sbuf_l = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
         for (int kit = 0; kit < nk; ++kit) {
             if (stamp_l) sbuf_l[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (stamp_l) sbuf_l[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
             const bool more = kit + 1 < nk;
@@ -865,7 +868,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         unsigned long long* sbuf = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
         for (int kit = 0; kit < nk; ++kit) {
             if (stamp) sbuf[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
-            __syncthreads();  // vmcnt(0) + barrier: step kit has landed, the other stage buffer is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // step kit has landed, the other stage buffer is free
             if (stamp) sbuf[kit * 4 + 1] = __builtin_amdgcn_s_memtime();
             const bool more = kit + 1 < nk;
             const char* base = smem + (kit & 1) * STAGE;
@@ -1291,6 +1295,342 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
+
+// ======================================================================================================
+// Row-shared-taps kernel for the 3x3 / pad 1 / stride 1 convolutions (w_layout == 2; slab_rows = image width W).
+// The per-stage cycle stamps of the kernel above show that a global_load_lds piece costs its wave 100-185 issue cycles while
+// LDS reads are in flight, and that the LDS port is the bound: bytes through DMA per MFMA is what counts.  The three taps of
+// one kernel row (dy; dx = -1, 0, +1) read the SAME source rows shifted by one token, so their A tile is loaded once: rows
+// m0 + dy*W - 1 .. m0 + dy*W + 128 (130 rows + padding to 136, the last one all zero) per (dy, 64-channel chunk), used by three
+// stages whose fragment reads go through row index r + dx + 1, or the zero row where the gather table says "padding" (image
+// edges, sample boundaries).  K order: (dy, chunk, dx) - the weight tile of a stage is simply addressed at column
+// (3*dy + dx + 4... tap)*C + chunk*64 of the ordinary [n][tap*C + c] operand, no re-layout.  DMA pieces per three taps:
+// 34 (A) + 120 (W) instead of 96 + 120.  An identity second source (the 1x1 skip of a ResBlock) follows as ordinary stages.
+// Tile 128 x 160, 8 waves = 2 K-halves x (2 x 2) waves of 64 x 80 on v_mfma_f32_16x16x32_bf16, the second K-half group one
+// stage late (stagger), epilogue shared with the kernel above.
+template <int NPASS>
+__global__ void __launch_bounds__(512, 1) wd_conv3_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+    constexpr int BM = 128, BN = 160;
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int AR = 136;                 // rows of an A tile (130 used, row 135 = zero row)
+    constexpr int A_PL = AR * 128, B_PL = BN * 128;
+    constexpr int ABUF = NPL * A_PL, WBUF = NPL * B_PL;
+    constexpr int APCS = NPL * (AR / 8), WPCS = NPL * (BN / 8);   // DMA pieces per tile
+    constexpr int A_INS = (APCS + 7) / 8, W_INS = (WPCS + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                        // [2][NPL][AR][128 B]
+    char* sW = smem + 2 * ABUF;             // [2][NPL][BN][128 B]
+    int* s_tab = reinterpret_cast<int*>(smem + 2 * ABUF + 2 * WBUF);  // [9][BM] source row of src[0] per tap, -1 = padding
+
+    const int ntile = nbn * nbm;
+    const int nwg = ntile * a.ksplit;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int sidx = wg / ntile;
+    wg -= sidx * ntile;
+    const int bn_i = wg % nbn, bm_i = wg / nbn;
+    const int m0 = bm_i * BM, n0 = bn_i * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, kh = wave >> 2;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const int Wimg = a.slab_rows;
+
+    {
+        const int32_t* g0 = a.src[0].gather;
+        const int hw_src0 = a.src[0].hw_src;
+        for (int idx = tid; idx < 9 * BM; idx += 512) {
+            const int t = idx / BM, row = idx - t * BM;
+            const int m = m0 + row;
+            int v = -1;
+            if (m < a.m) {
+                const int b = m / a.hw_out, p = m - b * a.hw_out;
+                const int g = g0[t * a.hw_out + p];
+                if (g >= 0) v = b * hw_src0 + g;
+            }
+            s_tab[idx] = v;
+        }
+    }
+    const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
+    const int C0 = a.src[0].c, nc0 = C0 / 64;
+    const int nq0 = 9 * nc0;                              // stages of the convolution
+    const int nk_all = a.ktot / 64;                       // + C1 / 64 identity stages
+    const int k_begin = (int)((long)nk_all * sidx / a.ksplit), k_end = (int)((long)nk_all * (sidx + 1) / a.ksplit);
+    const int nk = k_end - k_begin;
+    const long rows_src0 = (long)(a.m / a.hw_out) * a.src[0].hw_src;   // rows of the source planes (== a.m for a 'same' conv)
+
+    // stage state (wave-uniform, advanced incrementally - no divisions in the loop): conv stages run (dy, chunk, dx), then the
+    // identity stages; G = group id (one A tile per group), kcol = first weight column of the stage
+    struct Stg { int conv, dyi, chunk, dxi, G; long kcol; };
+    auto stage_at = [&](int q) {
+        Stg t;
+        if (q < nq0) {
+            t.conv = 1;
+            t.dyi = q / (3 * nc0);
+            const int rem = q - t.dyi * 3 * nc0;
+            t.chunk = rem / 3;
+            t.dxi = rem - t.chunk * 3;
+            t.G = q / 3;
+            t.kcol = (long)(t.dyi * 3 + t.dxi) * C0 + t.chunk * 64;
+        } else {
+            t.conv = 0; t.dyi = 1; t.chunk = q - nq0; t.dxi = 0;
+            t.G = nq0 / 3 + t.chunk;
+            t.kcol = (long)9 * C0 + (long)t.chunk * 64;
+        }
+        return t;
+    };
+    auto next_of = [&](Stg t) {   // the stage after t
+        if (t.conv) {
+            if (++t.dxi == 3) {
+                t.dxi = 0;
+                ++t.G;
+                if (++t.chunk == nc0) {
+                    t.chunk = 0;
+                    if (++t.dyi == 3) { t.conv = 0; t.dyi = 1; }
+                }
+            }
+            t.kcol = t.conv ? (long)(t.dyi * 3 + t.dxi) * C0 + t.chunk * 64 : (long)9 * C0;
+        } else {
+            ++t.chunk; ++t.G; t.kcol += 64;
+        }
+        return t;
+    };
+    // static part of this lane's DMA slots: slot i = piece wave + 8 i -> (plane, 8-row piece)
+    int a_j[A_INS];                     // tile row of the A slots
+    long a_ro0[A_INS], a_ro1[A_INS];    // tile row * ld + swizzled chunk, for src[0] / src[1]
+    long w_off[W_INS];                  // n * ktot + swizzled chunk of the W slots, -1 = zero line
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) {
+        const int pc = wave + 8 * i, rp = pc % (AR / 8);
+        a_j[i] = rp * 8 + lrow;
+        const int sw = (lpos ^ ((a_j[i] >> 1) & 7)) * 8;
+        a_ro0[i] = (long)a_j[i] * a.src[0].ld + sw;
+        a_ro1[i] = a.nsrc > 1 ? (long)a_j[i] * a.src[1].ld + sw : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INS; ++i) {
+        const int pc = wave + 8 * i, rp = pc % (BN / 8);
+        const int row = rp * 8 + lrow, n = n0 + row;
+        w_off[i] = (pc < WPCS && n < a.n) ? (long)n * a.ktot + (lpos ^ ((row >> 1) & 7)) * 8 : -1;
+    }
+    // source pointer of one DMA slot of the A tile of stage-state t / of its W tile (zero line where there is nothing to load)
+    auto ptr_A = [&](const Stg& t, int i) -> const wd_bf16* {
+        const int pc = wave + 8 * i;
+        const int pl = pc / (AR / 8);
+        const long srow0 = t.conv ? (long)m0 + (long)(t.dyi - 1) * Wimg - 1 : (long)m0;   // source row of tile row 0 (uniform)
+        const long sr = srow0 + a_j[i];
+        const bool ok = pc < APCS && a_j[i] < (t.conv ? 130 : 128) && sr >= 0 && sr < (t.conv ? rows_src0 : (long)a.m);
+        const wd_bf16* base = t.conv ? (pl ? a.src[0].lo : a.src[0].hi) + srow0 * a.src[0].ld + t.chunk * 64
+                                     : (pl ? a.src[1].lo : a.src[1].hi) + srow0 * a.src[1].ld + t.chunk * 64;
+        return ok ? base + (t.conv ? a_ro0[i] : a_ro1[i]) : zline;
+    };
+    auto ptr_W = [&](long kcol, int i) -> const wd_bf16* {
+        const int pc = wave + 8 * i;
+        const int pl = pc / (BN / 8);
+        return w_off[i] >= 0 ? (pl ? a.w_lo : a.w_hi) + kcol + w_off[i] : zline;
+    };
+    // issue: destination of slot i is fixed by (wave, i): buffer G & 1 of sA / buffer q & 1 of sW
+    auto issue_A = [&](int G, int i, const wd_bf16* src) {
+        const int pc = wave + 8 * i;
+        if (pc >= APCS) return;
+        const int pl = pc / (AR / 8), rp = pc - pl * (AR / 8);
+        __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sA + (G & 1) * ABUF + pl * A_PL + rp * 1024), 16, 0, 0);
+    };
+    auto issue_W = [&](int q, int i, const wd_bf16* src) {
+        const int pc = wave + 8 * i;
+        if (pc >= WPCS) return;
+        const int pl = pc / (BN / 8), rp = pc - pl * (BN / 8);
+        __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sW + (q & 1) * WBUF + pl * B_PL + rp * 1024), 16, 0, 0);
+    };
+    auto fire_A1 = [&](const Stg& t, int i) { issue_A(t.G, i, ptr_A(t, i)); };
+    auto fire_W1 = [&](int q, long kcol, int i) { issue_W(q, i, ptr_W(kcol, i)); };
+    // slot of everything stage q+1 (state tn) needs that is not in LDS yet: W slots first, then (new group only) the A slots
+    auto prefetch_slot = [&](int q, const Stg& tn, bool newA, int sl) {
+        if (sl < W_INS) fire_W1(q + 1, tn.kcol, sl);
+        else if (newA) fire_A1(tn, sl - W_INS);
+    };
+    constexpr int NSL = W_INS + A_INS;
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
+    Stg cur = stage_at(k_begin < nk_all ? k_begin : 0);
+    if (nk > 0) {
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) fire_A1(cur, i);
+#pragma unroll
+        for (int i = 0; i < W_INS; ++i) fire_W1(k_begin, cur.kcol, i);
+    }
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int r0w = (wq >> 1) * 64, c0w = (wq & 1) * 80;
+    const int ch = kh * 4 + lq;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the gather table is complete
+    // which (tap, row) pairs of this lane's four fragment rows are real pixels: bit tap * 4 + i
+    unsigned long long vmask = 0ull;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (s_tab[t * BM + r0w + i * 16 + l15] >= 0) vmask |= 1ull << (t * 4 + i);
+    bf16x8 xa[4][NPL], xb[5][NPL];
+    auto read16 = [&](int q, const Stg& t) {
+        const char* ab = sA + (t.G & 1) * ABUF;
+        const char* wb = sW + (q & 1) * WBUF;
+        const unsigned vm = t.conv ? (unsigned)(vmask >> ((t.dyi * 3 + t.dxi) * 4)) & 15u : 15u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0w + i * 16 + l15;
+            const int j = (vm >> i) & 1u ? r + t.dxi : AR - 1;   // (identity stages: dxi = 0, rows beyond M are zero-filled)
+            const int ao = lds_off2(j, ch);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) xa[i][p] = *reinterpret_cast<const bf16x8*>(ab + p * A_PL + ao);
+        }
+#pragma unroll
+        for (int t5 = 0; t5 < 5; ++t5) {
+            const int bo = lds_off2(c0w + t5 * 16 + l15, ch);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) xb[t5][p] = *reinterpret_cast<const bf16x8*>(wb + p * B_PL + bo);
+        }
+    };
+    // the products of one stage; `pf`: issue the (pre-computed) DMA slots of stage q+1 between the four row groups - no address
+    // arithmetic between the MFMAs, a 16x16x32 MFMA leaves room for about two vector instructions
+    const wd_bf16* pw[W_INS];
+    const wd_bf16* pa[A_INS];
+    auto mfma16 = [&](bool pf, int q, int Gn, bool newA) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (NPL == 2) {
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], xb[t][0], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][NPL - 1], acc[i][t], 0, 0, 0);
+                }
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][0], acc[i][t], 0, 0, 0);
+            }
+            if (pf) {
+#pragma unroll
+                for (int sl = i * NSL / 4; sl < (i + 1) * NSL / 4; ++sl) {
+                    if (sl < W_INS) issue_W(q + 1, sl, pw[sl]);
+                    else if (newA) issue_A(Gn, sl - W_INS, pa[sl - W_INS]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool stamp = (a.dbg & 0x100) && blockIdx.x == 0 && lane == 0 && a.ws && a.ksplit == 1;
+    unsigned long long* sb = reinterpret_cast<unsigned long long*>(a.ws) + (long)wave * nk * 4;
+    if (kh == 1) {
+        // late group: DMA of the next stage first, then the previous stage's products, then this stage's fragments
+        for (int q = k_begin; q < k_end; ++q) {
+            if (stamp) sb[(q - k_begin) * 4 + 0] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed (the fence of
+            __syncthreads();                                  // __syncthreads does not have to wait for loads)
+            if (stamp) sb[(q - k_begin) * 4 + 1] = __builtin_amdgcn_s_memtime();
+            const Stg tn = next_of(cur);
+            if (q + 1 < k_end) {
+                const bool newA = tn.G != cur.G;
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) prefetch_slot(q, tn, newA, sl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q > k_begin) mfma16(false, q, 0, false);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamp) sb[(q - k_begin) * 4 + 2] = __builtin_amdgcn_s_memtime();
+            read16(q, cur);
+            if (stamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sb[(q - k_begin) * 4 + 3] = __builtin_amdgcn_s_memtime();
+            }
+            cur = tn;
+        }
+        if (nk > 0) mfma16(false, 0, 0, false);
+    } else {
+        for (int q = k_begin; q < k_end; ++q) {
+            if (stamp) sb[(q - k_begin) * 4 + 0] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage q has landed, the buffers of stage q-1 are free
+            if (stamp) sb[(q - k_begin) * 4 + 1] = __builtin_amdgcn_s_memtime();
+            const bool more = q + 1 < k_end;
+            const Stg tn = next_of(cur);
+            const bool newA = more && tn.G != cur.G;
+            read16(q, cur);
+            if (more) {  // addresses of the next stage's pieces, in the shadow of the fragment reads
+#pragma unroll
+                for (int i = 0; i < W_INS; ++i) pw[i] = ptr_W(tn.kcol, i);
+                if (newA) {
+#pragma unroll
+                    for (int i = 0; i < A_INS; ++i) pa[i] = ptr_A(tn, i);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamp) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sb[(q - k_begin) * 4 + 2] = __builtin_amdgcn_s_memtime();
+            }
+            mfma16(more, q, tn.G, newA);
+            if (stamp) sb[(q - k_begin) * 4 + 3] = __builtin_amdgcn_s_memtime();
+            cur = tn;
+        }
+    }
+    // ---- partial tiles -> fp32 LDS image (the two K-halves summed in a fixed order), then the shared epilogue
+    constexpr int LDE = BN + 4;
+    float* ep = reinterpret_cast<float*>(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int hh = 0; hh < 2; ++hh) {
+        if (kh == hh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* pe = ep + (r0w + i * 16 + 4 * lq + r) * LDE + c0w + t * 16 + l15;
+                        *pe = (hh == 0) ? acc[i][t][r] : *pe + acc[i][t][r];
+                    }
+        }
+        __syncthreads();
+    }
+    wd_epilogue_tail<BM, BN, 512>(a, ep, m0, n0, tid, sidx);
+}
+
+template <int NPASS>
+int launch_conv3(const wd_gemm_args& a, hipStream_t st) {
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int loop_smem = 2 * NPL * (136 + 160) * 128 + 9 * 128 * 4;
+    constexpr int red_smem = 128 * (160 + 4) * 4 + WD_STAT_SCRATCH;
+    constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_conv3_kernel<NPASS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                smem) != hipSuccess)
+            return WD_ELAUNCH;
+        attr_done = true;
+    }
+    const int nbn = (a.n + 159) / 160, nbm = (a.m + 127) / 128;
+    {
+        WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        hipLaunchKernelGGL((wd_conv3_kernel<NPASS>), dim3(nbn * nbm * a.ksplit), dim3(512), smem, st, a, nbn, nbm);
+    }
+    if (a.ksplit > 1) {
+        const int cpg = a.stat_part ? a.stat_cpg : 1;
+        if (40 % cpg == 0) return launch_reduce<128, 40>(a, st);
+        if (32 % cpg == 0) return launch_reduce<128, 32>(a, st);
+        return launch_reduce<128, 160>(a, st);
+    }
+    return wd_check_launch();
+}
+
 }  // namespace
 
 extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
@@ -1307,8 +1647,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if ((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) return WD_EINVAL;  // vector epilogue only
         if (a.tile == 0) a.tile = bm * 1000 + bn;  // keep 128-row panels (no 64x64 fallback)
     }
-    if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout != 0)) return WD_EINVAL;
-    if (a.w_layout != 0) a.ksplit = 1;
+    if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout == 1)) return WD_EINVAL;
+    if (a.w_layout == 1) a.ksplit = 1;
     if (a.nsrc < 1 || a.nsrc > 2 || (a.npass != 1 && a.npass != 3)) return WD_EINVAL;
     if (a.m <= 0 || a.n <= 0 || a.hw_out <= 0 || !a.w_hi || (a.npass == 3 && !a.w_lo)) return WD_EINVAL;
     if (!a.out_f32 && !a.out_hi) return WD_EINVAL;
@@ -1346,6 +1686,19 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
             default: return WD_EINVAL;
         }
 #undef WD_DISPATCH3
+    }
+    bool conv3 = false;
+    if (a.w_layout == 2) {
+        // row-shared taps (wd_conv3_kernel): 3x3 / pad 1 / stride 1 over images of width slab_rows, optional identity source.
+        // The operand layout is the ordinary one, so this is a hint: shapes the kernel does not cover take the generic path.
+        const wd_src& q0 = a.src[0];
+        conv3 = q0.ntaps == 9 && q0.gather && q0.c % 64 == 0 && a.slab_rows > 0 && q0.hw_src == a.hw_out &&
+                a.hw_out % a.slab_rows == 0 && a.act != WD_ACT_GEGLU && (a.tile == 0 || a.tile == 128160) &&
+                (a.nsrc == 1 || (!a.src[1].gather && a.src[1].ntaps == 1 && a.src[1].c % 64 == 0));
+        if (conv3) a.tile = 128160;
+        a.w_layout = 0;
+    } else if (a.w_layout != 0) {
+        return WD_EINVAL;
     }
     bool v2ok = (a.ktot % BK2 == 0) && !getenv("WDIFF_GEMM_V1");
     for (int s = 0; s < a.nsrc; ++s) v2ok = v2ok && (a.src[s].c % BK2 == 0);
@@ -1387,6 +1740,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3, 1>(a, st) : launch2<BM_, BN_, 1, 1>(a, st); \
     a.ksplit = 1;                                                                                   \
     return a.npass == 3 ? launch<BM_, BN_, 3>(a, st) : launch<BM_, BN_, 1>(a, st)
+    if (conv3 && v2ok) return a.npass == 3 ? launch_conv3<3>(a, st) : launch_conv3<1>(a, st);
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);
         case 128160:
