@@ -94,6 +94,10 @@ def main():
                 rd = (w[:, 2] - w[:, 1]).float()         # address prep + ds_read of the fragments (until they landed)
                 mf = (w[:, 3] - w[:, 2]).float()         # MFMA groups with the DMA issue interleaved
                 tot = (w[1:, 0] - w[:-1, 0]).float()
+                if a.stamps > 1:
+                    print("   stage durations:", [int(x) for x in tot[3:21].tolist()])
+                    print("   wait:", [int(x) for x in wait[3:21].tolist()])
+                    print("   mfma:", [int(x) for x in mf[3:21].tolist()])
                 print(f"{name} wave {wv}: per stage (s_memtime ticks, 100 MHz?) wait {wait[2:-1].mean():.1f}  frag-read {rd[2:-1].mean():.1f}  "
                       f"mfma+dma {mf[2:-1].mean():.1f}  stage {tot[2:-1].mean():.1f}   whole loop {int(w[-1, 3] - w[0, 0])}")
             g.dbg = a.dbg
