@@ -577,3 +577,37 @@ def test_training_in_single_pass_bf16_mode():
             continue
         worst = max(worst, rel_err(grads["bf16"][k].cpu(), g.cpu()))
     assert 1e-4 < worst < 0.15, worst
+
+
+@pytest.mark.parametrize("cfg_name,variant,B,hw,phosc_len", [("FULL", "base", 1, (8, 32), 0), ("FULL", "base", 3, (8, 16), 0),
+                                                              ("FULL", "base", 5, (4, 8), 0), ("SMALL", "base", 65, (8, 32), 0),
+                                                              ("FULL", "phosc", 2, (8, 16), 769), ("DEEP", "phosc", 3, (8, 32), 5),
+                                                              ("SMALL", "base", 2, (2, 4), 0)])
+def test_forward_ragged_shapes_match_oracle(cfg_name, variant, B, hw, phosc_len):
+    """Batch sizes and latent sizes away from the benchmark shape (tails of the 128-row GEMM panels, of the 32-token folded
+    attention tiles, of the GroupNorm chunks; 64x128 and 32x64 images; a 65-sample batch) against the oracle."""
+    cfg = {"SMALL": SMALL, "DEEP": DEEP, "FULL": FULL}[cfg_name]
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    seed = 17
+    shapes = U.state_dict_shapes(cfg, variant)
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, seed)) for k, s in shapes}
+    orc = U.UNetOracle(cfg, sd, variant, phosc_len > 0)
+    inp = synthetic_inputs(B, seed=B * 7 + hw[1], hw=hw, num_classes=cfg["num_classes"], phosc_len=phosc_len)
+    with torch.no_grad():
+        ref = orc(inp["x"], inp["t"], inp["context"], inp["y"], inp.get("phosc"))
+    m = build(cfg, variant, phosc_len > 0, seed=seed)
+    out = call(m, variant, inp["x"], inp["t"], inp["context"], inp["y"], inp.get("phosc"))
+    assert out.shape == ref.shape
+    assert max_rel(out.cpu(), ref) < 1e-4
+    # and through the sampler (tabulated FiLM path, folded attention, graph): 3 steps from the same start
+    if variant == "base" and B <= 5:
+        T = 4
+        args = make_args(device=DEV)
+        diff = Diffusion(noise_steps=T, img_size=(hw[0] * 8, hw[1] * 8), args=args)
+        words = ["ab", "Word", "x", "Hello", "zz"][:B]
+        tf = torch.tensor(np.array([D.label_padding(w) for w in words], dtype="int64"))
+        noise = [torch.randn(B, 4, *hw, generator=torch.Generator().manual_seed(i)) for i in range(T - 2)]
+        got = diff.sampling(m, None, B, words, inp["y"], args, x_T=inp["x"], noise=noise)
+        with torch.no_grad():
+            want = D.sampling(lambda x, t: orc(x, t, tf, inp["y"]), inp["x"], noise, T)
+        assert max_rel(got.cpu(), want) < 2e-4
