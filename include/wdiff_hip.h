@@ -243,7 +243,8 @@ int wd_mse_loss(const float* pred, const float* target, int64_t n, float* grad, 
  *  d(input)  = wd_gemm over d(output) planes with the mirrored gather table and transposed weights;
  *  d(weight) = wd_gemm over the token dimension, operands = the transposed planes made by wd_transpose_planes. */
 
-/* out[(t*c + ch)][mm] (tap_minor = 0) or out[(ch*ntaps + t)][mm] (tap_minor = 1: the OIHW order of a conv weight)
+/* (weight gradient of nn.Conv2d / nn.Linear, unet.py:595,621,632,540,488,364,375,175-183,125,145,1201-1205,611 under autograd)
+ * out[(t*c + ch)][mm] (tap_minor = 0) or out[(ch*ntaps + t)][mm] (tap_minor = 1: the OIHW order of a conv weight)
  *   = in[src(mm, t)][ch] for mm < m (0 beyond, up to mpad): split-bf16 planes [ntaps*c][mpad].
  * in: planes (in_is_f32 = 0; in_lo may be NULL) or one fp32 matrix (in_is_f32 = 1, split on the fly); src = row mm, or
  * through the 3x3 gather table as in wd_gemm (zero row for -1). */
@@ -251,7 +252,8 @@ int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int
                         int hw_out, int hw_src, int m, int mpad, int tap_minor, wd_bf16* out_hi, wd_bf16* out_lo,
                         void* stream);
 
-/* out[s][col] (+)= scale * sum over rows [s*seg, (s+1)*seg) of x[row][col]; fixed summation order.
+/* (bias gradients of the layers above; gradient of the FiLM vector emb_out[..., None, None], unet.py:660-661)
+ * out[s][col] (+)= scale * sum over rows [s*seg, (s+1)*seg) of x[row][col]; fixed summation order.
  * scratch: ceil(rows/seg) * ceil(seg/64) * c floats.  (bias gradients: seg = rows; FiLM gradient: seg = hw.) */
 int wd_colsum(const float* x, int ld, int rows, int c, int seg, float* out, int out_ld, int accumulate, float scale,
               float* scratch, int64_t scratch_floats, void* stream);
@@ -269,13 +271,13 @@ int wd_gn_bwd_apply(const float* x, int ld, const float* dz, int dz_ld, int dz_o
                     const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off, float eps,
                     int silu, const float* sums, float* dx, int dx_ld, int accumulate, void* stream);
 
-/* LayerNorm backward: dx (+=), and colpart[blk][2][c] (blk < wd_layernorm_bwd_nblk(rows)) whose column sums are
+/* LayerNorm backward (nn.LayerNorm of BasicTransformerBlock, unet.py:314-316): dx (+=), and colpart[blk][2][c] (blk < wd_layernorm_bwd_nblk(rows)) whose column sums are
  * [d gamma | d beta]. */
 int wd_layernorm_bwd_nblk(int rows);
 int wd_layernorm_bwd(const float* x, int ld, const float* dy, int dy_ld, int rows, int c, const float* gamma, float eps,
                      float* dx, int dx_ld, int accumulate, float* colpart, void* stream);
 
-/* softmax-attention backward for nk <= 16 keys: dq[B*nq][lddq]; dkv_part[b][nwg][2][nk][heads*d] = per-workgroup partial
+/* softmax-attention backward (CrossAttention.forward unet.py:185-279, Word_Attention :823-836) for nk <= 16 keys: dq[B*nq][lddq]; dkv_part[b][nwg][2][nk][heads*d] = per-workgroup partial
  * sums of (dK, dV) over their tokens (nwg returned; the caller column-sums them). */
 /* number of per-workgroup dK/dV partial slabs wd_attention_bwd_small writes per batch element (0 = unsupported shape) */
 int wd_attention_bwd_small_nwg(int heads, int nq, int nk, int d);
@@ -294,7 +296,8 @@ int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf
 int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate, float scale,
                      void* stream);
 
-/* Attention backward for any number of keys <= 1024 (spatial self-attention, the 779-token PHOSC context): recomputes the
+/* Attention backward (CrossAttention.forward unetPhosc.py:157-198, Word_Attention :696-708) for any number of keys <= 1024
+ * (spatial self-attention, the 779-token PHOSC context): recomputes the
  * softmax rows, dq/dk/dv written in place of autograd's (row pitches ldd*; head h owns columns [h*d, (h+1)*d)).
  * scratch: wd_attention_bwd_scratch_floats() floats (P and dS, [batch][heads][nq][nk] each).  Deterministic. */
 int64_t wd_attention_bwd_scratch_floats(int batch, int heads, int nq, int nk);
@@ -309,15 +312,15 @@ int wd_add(float* dst, const float* src, int64_t n, void* stream);
 /* packed weight gradient [n][tap*c + ch] (row pitch ld >= ntaps*c) -> the parameter's OIHW order [n][ch][tap]. */
 int wd_permute_dw(const float* packed, int ld, int n, int c, int ntaps, float* out, void* stream);
 
-/* GEGLU unfused (training keeps the pre-activation u = [a | g]): h = a * gelu_erf(g) -> planes; du from dh. */
+/* GEGLU (unet.py:122-135) unfused (training keeps the pre-activation u = [a | g]): h = a * gelu_erf(g) -> planes; du from dh. */
 int wd_geglu_fwd(const float* u, int ld, int64_t rows, int inner, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
 int wd_geglu_bwd(const float* u, int ld, const float* dh, int dh_ld, int64_t rows, int inner, float* du, int du_ld,
                  void* stream);
-/* dpre = dact * silu'(pre) */
+/* nn.SiLU backward (time_embed / emb_layers, unet.py:1201-1205,609): dpre = dact * silu'(pre) */
 int wd_silu_bwd(const float* pre, const float* dact, int64_t n, float* dpre, void* stream);
-/* backward of nearest x2 upsampling: in [B][2h][2w][c] -> out [B][h][w][c], 2x2 block sums */
+/* backward of F.interpolate(scale_factor=2, mode="nearest") (Upsample.forward, unet.py:497): in [B][2h][2w][c] -> out [B][h][w][c], 2x2 block sums */
 int wd_pool2x2_sum(const float* in, int batch, int h, int w, int c, float* out, void* stream);
-/* nn.Embedding backward: dtable[v][:] (+)= sum of d[r][:] over rows with ids[r] == v (deterministic) */
+/* nn.Embedding backward (CharacterEncoder.embedding unet.py:845, label_emb :1245): dtable[v][:] (+)= sum of d[r][:] over rows with ids[r] == v (deterministic) */
 int wd_embedding_bwd(const void* ids, int ids_are_i64, int rows, const float* d, int ld, int vocab, int c, float* dtable,
                      int accumulate, void* stream);
 
