@@ -202,6 +202,7 @@ def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
     if rank == 0:
         lib = N.lib()
         eager = TrainStep(model, diff, opt, seed=5, use_graph=False)
+        eager.world = 1  # rank-0-only profiling pass: no collective (the other ranks are not in it)
         eager(x, ctx, y)
         torch.cuda.synchronize()
         lib.wd_prof_enable(1)
@@ -229,7 +230,10 @@ def main():
                          "(configs[4] model: 779-token context, 256-token self-attention), reported as an extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=30, help="also time this many train.py-style steps (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=-1,
+                    help="also time this many train.py-style steps (0 = skip; default: 30 on one GPU, 0 on several - the "
+                         "multi-GPU run is the scaling measurement of the headline metric, pass a count to add the data-parallel "
+                         "training leg with its gradient all-reduce)")
     a = ap.parse_args()
 
     from worddiffusion_amd import dist as wdist
@@ -311,6 +315,8 @@ def main():
         cpu = cpu_baseline(min(os.cpu_count() or 1, 64))
 
     train = None
+    if a.train_steps < 0:
+        a.train_steps = 30 if world == 1 else 0
     if a.train_steps > 0 and a.variant == "base":
         del runner
         torch.cuda.empty_cache()
