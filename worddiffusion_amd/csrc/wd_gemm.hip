@@ -1223,24 +1223,49 @@ __global__ void __launch_bounds__(256) wd_gemm_reduce_kernel(const wd_gemm_args 
     const int tid = threadIdx.x;
     const long total = (long)a.m * a.n;
     const bool v4 = (a.n & 3) == 0;
-    for (int i = tid; i < BM * (BN / 4); i += 256) {
-        const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
-        const int m = m0 + row, n = n0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < a.m && n < a.n) {
-            if (v4) {
-                for (int sp = 0; sp < a.ksplit; ++sp) {
-                    const float4 q = *reinterpret_cast<const float4*>(a.ws + (long)sp * total + (long)m * a.n + n);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                }
-            } else {
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int sp = 0; sp < a.ksplit; ++sp)
-                    for (int j = 0; j < 4 && n + j < a.n; ++j) e[j] += a.ws[(long)sp * total + (long)m * a.n + n + j];
-                v = make_float4(e[0], e[1], e[2], e[3]);
+    if (v4) {
+        // slab-major with all of the thread's elements in flight per slab: the pass is latency-bound otherwise (one
+        // workgroup's worth of loads per CU).  Per element the slabs are still summed in ascending order.
+        constexpr int NI = (BM * (BN / 4) + 255) / 256;
+        float4 v[NI];
+        long off[NI];
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            const int i = tid + ii * 256;
+            const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + c;
+            v[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[ii] = (i < BM * (BN / 4) && m < a.m && n < a.n) ? (long)m * a.n + n : -1;
+        }
+        for (int sp = 0; sp < a.ksplit; ++sp) {
+            const float* slab = a.ws + (long)sp * total;
+            float4 q[NI];
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii)
+                q[ii] = off[ii] >= 0 ? *reinterpret_cast<const float4*>(slab + off[ii]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+                v[ii].x += q[ii].x; v[ii].y += q[ii].y; v[ii].z += q[ii].z; v[ii].w += q[ii].w;
             }
         }
-        *reinterpret_cast<float4*>(ep + row * LDE + c) = v;
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            const int i = tid + ii * 256;
+            if (i < BM * (BN / 4)) {
+                const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(ep + row * LDE + c) = v[ii];
+            }
+        }
+    } else {
+        for (int i = tid; i < BM * (BN / 4); i += 256) {
+            const int row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + c;
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.m && n < a.n)
+                for (int sp = 0; sp < a.ksplit; ++sp)
+                    for (int j = 0; j < 4 && n + j < a.n; ++j) e[j] += a.ws[(long)sp * total + (long)m * a.n + n + j];
+            *reinterpret_cast<float4*>(ep + row * LDE + c) = make_float4(e[0], e[1], e[2], e[3]);
+        }
     }
     __syncthreads();
     wd_gemm_args b = a;
@@ -1262,6 +1287,18 @@ int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
     WdLaunchScope scope(WD_CLS_GEMM_REDUCE, st);
     hipLaunchKernelGGL((wd_gemm_reduce_kernel<RM, RN>), dim3(rbn * rbm), dim3(256), rsmem, st, a, rbn);
     return wd_check_launch();
+}
+
+// the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups per tile
+// when the GroupNorm sums are fused in).  The statistics layout is indexed by chunks of BM rows when a sample has more
+// rows than that, so the 64-row tile is only used where it leaves that layout unchanged (samples of <= 64 rows).
+template <int BM, int BN>
+int launch_reduce_any(const wd_gemm_args& a, hipStream_t st) {
+    const int cpg = a.stat_part ? a.stat_cpg : 1;
+    const bool half_rows = BM == 128 && (!a.stat_part || (a.hw_out <= 64 && 64 % a.hw_out == 0));
+    if (40 % cpg == 0) return half_rows ? launch_reduce<64, 40>(a, st) : launch_reduce<128, 40>(a, st);
+    if (32 % cpg == 0) return half_rows ? launch_reduce<64, 32>(a, st) : launch_reduce<128, 32>(a, st);
+    return launch_reduce<BM, BN>(a, st);
 }
 
 template <int BM, int BN, int NPASS, int KS, bool PP = false, bool M16 = false>
@@ -1287,10 +1324,7 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
     if (a.ksplit > 1) {
         // the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups
         // per tile when the GroupNorm sums are fused in)
-        const int cpg = a.stat_part ? a.stat_cpg : 1;
-        if (40 % cpg == 0) return launch_reduce<128, 40>(a, st);
-        if (32 % cpg == 0) return launch_reduce<128, 32>(a, st);
-        return launch_reduce<BM, BN>(a, st);
+        return launch_reduce_any<BM, BN>(a, st);
     }
     return wd_check_launch();
 }
@@ -1623,10 +1657,7 @@ int launch_conv3(const wd_gemm_args& a, hipStream_t st) {
         hipLaunchKernelGGL((wd_conv3_kernel<NPASS>), dim3(nbn * nbm * a.ksplit), dim3(512), smem, st, a, nbn, nbm);
     }
     if (a.ksplit > 1) {
-        const int cpg = a.stat_part ? a.stat_cpg : 1;
-        if (40 % cpg == 0) return launch_reduce<128, 40>(a, st);
-        if (32 % cpg == 0) return launch_reduce<128, 32>(a, st);
-        return launch_reduce<128, 160>(a, st);
+        return launch_reduce_any<128, 160>(a, st);
     }
     return wd_check_launch();
 }
