@@ -1749,7 +1749,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         a.ksplit = 1;
         const int bn = tile % 1000, bm = tile / 1000;
         const long tiles = (long)((a.m + bm - 1) / bm) * ((a.n + bn - 1) / bn);
-        if (v2ok && a.ws && a.act != WD_ACT_GEGLU && tiles < 128 && nk64 >= 8) {
+        // half-filled chip (exactly 128 tiles, e.g. batch 32): a two-way cut pays on the long-K convolutions only
+        if (v2ok && a.ws && a.act != WD_ACT_GEGLU && (tiles < 128 || (tiles == 128 && nk64 >= 32)) && nk64 >= 8) {
             long sp = 256 / tiles;
             if (sp > nk64 / 4) sp = nk64 / 4;
             if (sp > 8) sp = 8;
