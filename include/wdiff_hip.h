@@ -95,7 +95,8 @@ typedef struct wd_gemm_args {
                            * nchunk = max(1, hw_out / 128).  Needs 128-row tiles, hw_out | 128 or 128 | hw_out, whole
                            * groups per column tile; not with GEGLU */
     int32_t stat_cpg;     /* channels per statistics group */
-    int32_t dbg;          /* must be 0; nonzero values switch parts of the kernel off for timing experiments (results invalid) */
+    int32_t dbg;          /* 0 in production.  0x400: take the two-workgroups-per-CU kernel (wd_gemm4_kernel) wherever it is
+                             legal, whatever the grid size (parity tests); other bits are timing experiments */
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);

@@ -38,7 +38,7 @@ SLAB = [False, True]
 
 
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0):
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0, dbg=0):
     """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
     slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
@@ -82,6 +82,7 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
         args.out_hi, args.out_lo, args.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), n_out
     args.tile = tile
     args.ksplit = ksplit
+    args.dbg = dbg
     if ksplit != 1:
         ws = torch.empty(max(ksplit, 8) * m * n, device=DEV)
         keep.append(ws)
@@ -206,6 +207,46 @@ def test_gemm_split_k(ksplit):
     out2, _ = run_gemm(srcs, wcat.to(DEV), m, hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV),
                        ksplit=ksplit)
     assert torch.equal(out, out2)  # deterministic
+
+
+@pytest.mark.parametrize("B,hh,ww,c1,c2,n,ksplit", [(4, 4, 16, 320, 640, 320, 1), (3, 8, 32, 64, 0, 160, 1), (5, 5, 7, 128, 64, 200, 1),
+                                                      (4, 4, 16, 320, 640, 320, 3), (64, 8, 32, 64, 0, 320, 1)])
+def test_gemm_two_workgroups_per_cu_kernel(B, hh, ww, c1, c2, n, ksplit):
+    """wd_gemm4_kernel (32-deep stages, four waves, 64-row half epilogues; dbg 0x400 forces it): 3x3 gather source + optional
+    identity skip source, FiLM row vector, residual, planes out, ragged M / N, split-K - vs fp64, and vs the v2 kernel."""
+    g = torch.Generator().manual_seed(B + hh + ww + c1 + n)
+    hw, m = hh * ww, B * hh * ww
+    a1 = torch.randn(m, c1, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    wcat = torch.randn(n, 9 * c1 + c2, generator=g) / (9 * c1 + c2) ** 0.5
+    bias, film, res = torch.randn(n, generator=g), torch.randn(B, n, generator=g), torch.randn(m, n, generator=g)
+    x1 = a1.reshape(B, hh, ww, c1).permute(0, 3, 1, 2)
+    ref = (F.conv2d(x1.double(), wcat[:, :9 * c1].reshape(n, 3, 3, c1).permute(0, 3, 1, 2).double(), padding=1)
+           .permute(0, 2, 3, 1).reshape(m, n) + bias.double() + film.double().repeat_interleave(hw, 0) + res.double())
+    srcs = [(planes_of(a1.to(DEV)), c1, 9, torch.from_numpy(tab).to(DEV), hw)]
+    if c2:
+        a2 = torch.randn(m, c2, generator=g)
+        ref = ref + a2.double() @ wcat[:, 9 * c1:].double().t()
+        srcs.append((planes_of(a2.to(DEV)), c2, 1, None, 0))
+    kw = dict(bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV), want_planes=True, ksplit=ksplit, tile=128160)
+    out, pl = run_gemm(srcs, wcat.to(DEV), m, hw, dbg=0x400, **kw)
+    assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
+    out0, _ = run_gemm(srcs, wcat.to(DEV), m, hw, **kw)
+    assert max_rel(out.cpu(), out0.cpu()) < 5e-6
+
+
+def test_gemm_two_workgroups_per_cu_kernel_geglu():
+    g = torch.Generator().manual_seed(77)
+    m, dim, inner = 300, 320, 640
+    a = torch.randn(m, dim, generator=g)
+    w = torch.randn(2 * inner, dim, generator=g) / dim ** 0.5
+    b = torch.randn(2 * inner, generator=g)
+    h = a.double() @ w.double().t() + b.double()
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    for npass, tol in ((3, 2e-5), (1, 2e-2)):
+        out, pl = run_gemm([(planes_of(a.to(DEV)), dim, 1, None, 0)], geglu_interleave(w, 80).to(DEV), m, 1, npass=npass,
+                           bias=geglu_interleave(b, 80).to(DEV), act=N.ACT_GEGLU, want_planes=True, tile=128160, dbg=0x400)
+        assert rel_err(out.cpu(), ref) < tol and rel_err(unplanes(pl).cpu(), ref) < tol
 
 
 def test_gemm_rejects_bad_arguments():

@@ -893,6 +893,228 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
 }
 
 // ======================================================================================================
+// v4: the 128 x 160 tile with 32-deep stages and FOUR waves (64 x 80 wave tiles of 16x16x32 MFMAs, one MFMA k-step per
+// stage).  Two stage buffers are 72 KB, so TWO workgroups share a CU: they run out of phase without sharing a barrier, so
+// one's prologue / epilogue / DMA-issue stalls sit under the other's MFMAs - which is what the short-K layers (GEGLU
+// projection, 1x1 convolutions, attention projections: 5-20 stages) lack in the one-workgroup-per-CU kernel above.
+// LDS rows are 64 bytes (lds_off swizzle); a DMA piece is 16 rows.  The fp32 epilogue image of the whole tile does not
+// fit beside a second workgroup, so the epilogue runs over the two 64-row halves in turn; GroupNorm statistics (whose
+// layout is tied to 128-row panels) stay with the v2 kernel.
+template <int NPASS>
+__global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+    constexpr int BM = 128, BN = 160, BK = 32;
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int A_PL = BM * 64, B_PL = BN * 64;
+    constexpr int STAGE = NPL * (A_PL + B_PL);
+    constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;
+    constexpr int A_INS = A_PIECES / 4, B_INS = (B_PIECES + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE);  // [ntaps0][BM] source row of src[0] per tap, -1 = zero row
+
+    const int ntile = nbn * nbm;
+    const int nwg = ntile * a.ksplit;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int sidx = wg / ntile;
+    wg -= sidx * ntile;
+    const int bn_i = wg % nbn, bm_i = wg / nbn;
+    const int m0 = bm_i * BM, n0 = bn_i * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 2, lpos = lane & 3;
+    const int sw = (lpos ^ ((lane >> 4) & 3)) * 8;  // source chunk (elements) that lands at position lpos of row lrow
+
+    {
+        const int nt0 = a.src[0].ntaps;
+        const int32_t* g0 = a.src[0].gather;
+        const int hw_src0 = a.src[0].hw_src;
+        for (int idx = tid; idx < nt0 * BM; idx += 256) {
+            const int t = idx / BM, row = idx - t * BM;
+            const int m = m0 + row;
+            int v = -1;
+            if (m < a.m) {
+                if (g0) {
+                    const int b = m / a.hw_out, p = m - b * a.hw_out;
+                    const int g = g0[t * a.hw_out + p];
+                    if (g >= 0) v = b * hw_src0 + g;
+                } else {
+                    v = m;
+                }
+            }
+            s_tab[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    long b_off[B_INS];
+    bool b_ok[B_INS];
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i) {
+        const int piece = wave + 4 * i;
+        const int n = n0 + piece * 16 + lrow;
+        b_ok[i] = (piece < B_PIECES) && (n < a.n);
+        b_off[i] = (long)n * a.ktot + sw;
+    }
+    const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
+
+    const int nk_all = a.ktot / BK;
+    const int k_begin = (int)((long)nk_all * sidx / a.ksplit), k_end = (int)((long)nk_all * (sidx + 1) / a.ksplit);
+    int s = 0, tap = 0, kc = 0;
+    const wd_bf16* cur_hi = a.src[0].hi;
+    const wd_bf16* cur_lo = a.src[0].lo;
+    int cur_ld = a.src[0].ld, cur_c = a.src[0].c, cur_nt = a.src[0].ntaps;
+    {
+        const int cpt = a.src[0].c / BK, n0st = a.src[0].ntaps * cpt;
+        if (k_begin < n0st) {
+            tap = k_begin / cpt;
+            kc = k_begin - tap * cpt;
+        } else {
+            s = 1;
+            kc = k_begin - n0st;
+            cur_hi = a.src[1].hi;
+            cur_lo = a.src[1].lo;
+            cur_ld = a.src[1].ld;
+            cur_c = a.src[1].c;
+            cur_nt = a.src[1].ntaps;
+        }
+    }
+    long a_off[A_INS];
+    auto locate = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) {
+            const int row = (wave + 4 * i) * 16 + lrow;
+            int r;
+            if (s == 0) r = s_tab[tap * BM + row];
+            else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
+            a_off[i] = r >= 0 ? (long)r * cur_ld + sw : -1;
+        }
+    };
+    locate();
+    auto issue_a = [&](int i, char* sbase) {
+        const int piece = wave + 4 * i;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            const wd_bf16* src = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK : zline;
+            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int i, int kit, char* sbase) {
+        const int piece = wave + 4 * i;
+        if (piece < B_PIECES) {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const wd_bf16* src = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK : zline;
+                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16, 0,
+                                                 0);
+            }
+        }
+    };
+    auto issue = [&](int kit, char* sbase) {
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) issue_a(i, sbase);
+#pragma unroll
+        for (int i = 0; i < B_INS; ++i) issue_b(i, kit, sbase);
+    };
+    auto advance = [&]() {
+        ++kc;
+        if (kc * BK == cur_c) {
+            kc = 0;
+            ++tap;
+            if (tap == cur_nt) {
+                tap = 0;
+                ++s;
+                if (s < a.nsrc) {
+                    cur_hi = a.src[1].hi;
+                    cur_lo = a.src[1].lo;
+                    cur_ld = a.src[1].ld;
+                    cur_c = a.src[1].c;
+                    cur_nt = a.src[1].ntaps;
+                }
+            }
+            if (s < a.nsrc) locate();
+        }
+    };
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
+
+    const int nk = k_end - k_begin;
+    if (nk > 0) {
+        issue(k_begin, smem);
+        advance();
+    }
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int r0w = (wave >> 1) * 64, c0w = (wave & 1) * 80;
+    for (int kit = 0; kit < nk; ++kit) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage kit has landed; every wave is done reading the other buffer
+        const char* base = smem + (kit & 1) * STAGE;
+        // the next stage's DMA goes out first: it then has the whole stage to land, and while this wave is held up in the
+        // issue the co-resident workgroup fills the MFMA pipe (issuing between the MFMA groups, or after the fragment
+        // reads, both measured 4-7 % slower on the GEGLU projection)
+        if (kit + 1 < nk) {
+            issue(k_begin + kit + 1, smem + ((kit + 1) & 1) * STAGE);
+            advance();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 xa[4][NPL], xb[5][NPL];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ao = lds_off(r0w + i * 16 + l15, lq);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) xa[i][p] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + ao);
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int bo = NPL * A_PL + lds_off(c0w + t * 16 + l15, lq);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) xb[t][p] = *reinterpret_cast<const bf16x8*>(base + p * B_PL + bo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (NPL == 2) {
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], xb[t][0], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][NPL - 1], acc[i][t], 0, 0, 0);
+                }
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], xb[t][0], acc[i][t], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue over the two 64-row halves of the tile in turn (fp32 LDS image of 64 x 160)
+    constexpr int LDE = BN + 4;
+    float* ep = reinterpret_cast<float*>(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int half = 0; half < 2; ++half) {
+        if ((wave >> 1) == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ep[(i * 16 + 4 * lq + r) * LDE + c0w + t * 16 + l15] = acc[i][t][r];
+        }
+        __syncthreads();
+        wd_epilogue_tail<64, BN, 256>(a, ep, m0 + half * 64, n0, tid, sidx);
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================
 // v3 "slab" kernel: the A operand of a 3x3 convolution is NOT re-fetched per tap.  For a panel of BM output rows
 // the union of source rows over all taps is a short contiguous range (a few image rows + halo): that slab is
 // DMA'd into LDS once per 32-channel chunk (double buffered, prefetched one chunk ahead) and all nine taps read
@@ -1299,6 +1521,28 @@ int launch_reduce_any(const wd_gemm_args& a, hipStream_t st) {
     if (40 % cpg == 0) return half_rows ? launch_reduce<64, 40>(a, st) : launch_reduce<128, 40>(a, st);
     if (32 % cpg == 0) return half_rows ? launch_reduce<64, 32>(a, st) : launch_reduce<128, 32>(a, st);
     return launch_reduce<BM, BN>(a, st);
+}
+
+template <int NPASS>
+int launch4(const wd_gemm_args& a, hipStream_t st) {
+    constexpr int NPL = (NPASS == 1) ? 1 : 2;
+    constexpr int smem = 2 * NPL * (128 + 160) * 64 + 9 * 128 * 4;
+    static_assert(64 * 164 * 4 <= 2 * NPL * (128 + 160) * 64 || NPASS == 1, "epilogue image must fit the stage buffers");
+    constexpr int smem_need = smem > 64 * 164 * 4 ? smem : 64 * 164 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemm4_kernel<NPASS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_need) != hipSuccess)
+            return WD_ELAUNCH;
+        attr_done = true;
+    }
+    const int nbn = (a.n + 159) / 160, nbm = (a.m + 127) / 128;
+    {
+        WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        hipLaunchKernelGGL((wd_gemm4_kernel<NPASS>), dim3(nbn * nbm * a.ksplit), dim3(256), smem_need, st, a, nbn, nbm);
+    }
+    if (a.ksplit > 1) return launch_reduce_any<128, 160>(a, st);
+    return wd_check_launch();
 }
 
 template <int BM, int BN, int NPASS, int KS, bool PP = false, bool M16 = false>
@@ -1777,6 +2021,14 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         case 128064: WD_DISPATCH(128, 64);
         case 128160:
             // second K-half group runs one stage late (see the kernel); the extra drain phase only pays on long K loops
+            {
+                // two co-resident 4-wave workgroups per CU for the layers without fused statistics (see wd_gemm4_kernel)
+                // WDIFF_GEMM_V4: 0 never, 1 always (where legal), default 2 = when every CU gets at least two workgroups
+                static const int v4_env = getenv("WDIFF_GEMM_V4") ? atoi(getenv("WDIFF_GEMM_V4")) : 2;
+                const long wgs = (long)((a.m + 127) / 128) * ((a.n + 159) / 160) * a.ksplit;
+                if (v2ok && !a.stat_part && (v4_env == 1 || (v4_env == 2 && wgs >= 512) || (a.dbg & 0x400)))
+                    return a.npass == 3 ? launch4<3>(a, st) : launch4<1>(a, st);
+            }
             if (v2ok && ks == 2 && m16 && stagger && nk64 / a.ksplit >= stagger_min) a.dbg |= 0x200;
             if (v2ok && ks == 2 && m16)
                 return a.npass == 3 ? launch2<128, 160, 3, 2, false, true>(a, st) : launch2<128, 160, 1, 2, false, true>(a, st);
