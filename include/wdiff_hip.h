@@ -333,8 +333,9 @@ int wd_graph_destroy(void* graph_exec);
 
 /* per-kernel-class timing with hipEvents recorded on the launch stream (bench.py roofline leg).
  * classes: 0 gemm (the dominant wd_gemm2_kernel<128,160,...>; gemm_flops counts its 2*M*N*K), 1 gn_stats, 2 gn_apply,
- * 3 layernorm, 4 attention, 5 other, 6 gemm with other tile shapes, 7 split-K combine pass. */
-#define WD_NCLASS 8
+ * 3 layernorm, 4 attention, 5 other, 6 gemm with other tile shapes, 7 split-K combine pass, 8 the two-workgroups-per-CU
+ * gemm kernel (wd_gemm4_kernel). */
+#define WD_NCLASS 9
 int wd_prof_enable(int on);
 int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
 

@@ -13,6 +13,7 @@
 #define WD_CLS_OTHER 5
 #define WD_CLS_GEMM_OTHER 6   // wd_gemm tile shapes other than the dominant 128x160 kernel
 #define WD_CLS_GEMM_REDUCE 7  // split-K combine pass
+#define WD_CLS_GEMM_2CU 8     // wd_gemm4_kernel (two workgroups per CU)
 
 // ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
 extern "C" int wd_prof_is_on();

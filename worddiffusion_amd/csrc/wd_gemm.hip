@@ -1538,7 +1538,7 @@ int launch4(const wd_gemm_args& a, hipStream_t st) {
     }
     const int nbn = (a.n + 159) / 160, nbm = (a.m + 127) / 128;
     {
-        WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        WdLaunchScope scope(WD_CLS_GEMM_2CU, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
         hipLaunchKernelGGL((wd_gemm4_kernel<NPASS>), dim3(nbn * nbm * a.ksplit), dim3(256), smem_need, st, a, nbn, nbm);
     }
     if (a.ksplit > 1) return launch_reduce_any<128, 160>(a, st);
