@@ -237,9 +237,13 @@ def main():
     a = ap.parse_args()
 
     from worddiffusion_amd import dist as wdist
-    rank, world, local = wdist.init_process_group("nccl")  # no-op for a single process
-    if world == 1:
+    # WDIFF_BENCH_REHEARSE=1: every rank on cuda:0 with gloo - rehearses the N>1 control flow on a one-GPU box (numbers from
+    # such a run mean nothing; RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("WDIFF_BENCH_REHEARSE", "0") == "1"
+    rank, world, local = wdist.init_process_group("gloo" if rehearse else "nccl")  # no-op for a single process
+    if world == 1 or rehearse:
         torch.cuda.set_device(0)
+        local = 0
     dev = f"cuda:{local if world > 1 else 0}"
     B = a.batch
 
