@@ -363,6 +363,9 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int ld, const f
 // dy * xhat (-> d gamma) and dy (-> d beta): colpart[blk][c][2]
 constexpr int LB_MAX4 = 8;
 constexpr int LB_ROWS = 16;
+// MAX4 = float4 per lane and row (c <= 256 MAX4): the per-lane row image and the column sums live in registers, so the small
+// instantiation (c <= 512) runs at full occupancy where the general one is limited to two waves per SIMD
+template <int MAX4>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy,
                                                             int dy_ld, int rows, int c, const float* __restrict__ gamma,
                                                             float eps, float* __restrict__ dx, int dx_ld, int accumulate,
@@ -371,17 +374,17 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
     float* s_col = reinterpret_cast<float*>(smem);  // [4 waves][c][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = c >> 2;
-    float4 ag[LB_MAX4], ab[LB_MAX4];
+    float4 ag[MAX4], ab[MAX4];
 #pragma unroll
-    for (int i = 0; i < LB_MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int r0 = blockIdx.x * LB_ROWS;
     for (int rr = wave; rr < LB_ROWS; rr += 4) {
         const int row = r0 + rr;
         if (row >= rows) break;
-        float4 v[LB_MAX4], d[LB_MAX4];
+        float4 v[MAX4], d[MAX4];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LB_MAX4; ++i) {
+        for (int i = 0; i < MAX4; ++i) {
             const int f = lane + 64 * i;
             if (f < c4) {
                 v[i] = *reinterpret_cast<const float4*>(x + (long)row * ld + f * 4);
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         const float mean = wd_wave_sum(s) / (float)c;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LB_MAX4; ++i) {
+        for (int i = 0; i < MAX4; ++i) {
             const int f = lane + 64 * i;
             if (f < c4) {
                 const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         const float rstd = 1.0f / sqrtf(wd_wave_sum(q) / (float)c + eps);
         float t1 = 0.f, t2 = 0.f;  // sum(dxhat), sum(dxhat * xhat)
 #pragma unroll
-        for (int i = 0; i < LB_MAX4; ++i) {
+        for (int i = 0; i < MAX4; ++i) {
             const int f = lane + 64 * i;
             if (f < c4) {
                 const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         t1 = wd_wave_sum(t1) / (float)c;
         t2 = wd_wave_sum(t2) / (float)c;
 #pragma unroll
-        for (int i = 0; i < LB_MAX4; ++i) {
+        for (int i = 0; i < MAX4; ++i) {
             const int f = lane + 64 * i;
             if (f < c4) {
                 float4 o;
@@ -436,7 +439,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int i = 0; i < LB_MAX4; ++i) {
+    for (int i = 0; i < MAX4; ++i) {
         const int f = lane + 64 * i;
         if (f < c4) {
             *reinterpret_cast<float4*>(s_col + (wave * 2) * c + f * 4) = ag[i];      // [wave][{d gamma, d beta}][c]
@@ -862,14 +865,180 @@ extern "C" int wd_layernorm_bwd(const float* x, int ld, const float* dy, int dy_
     if (c % 4 || ld % 4 || dy_ld % 4 || dx_ld % 4 || c > 64 * 4 * LB_MAX4) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(wd_layernorm_bwd_nblk(rows)), dim3(256), 4 * c * 2 * sizeof(float), st, x,
+if (c <= 512)
+            hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(wd_layernorm_bwd_nblk(rows)), dim3(256), 4 * c * 2 * sizeof(float), st, x,
+                       ld, dy, dy_ld, rows, c, gamma, eps, dx, dx_ld, accumulate, colpart);
+    else
+            hipLaunchKernelGGL(layernorm_bwd_kernel<LB_MAX4>, dim3(wd_layernorm_bwd_nblk(rows)), dim3(256), 4 * c * 2 * sizeof(float), st, x,
                        ld, dy, dy_ld, rows, c, gamma, eps, dx, dx_ld, accumulate, colpart);
     return wd_check_launch();
 }
 
+// Same contract as attn_bwd_small_kernel with more parallelism per token: a (token, head) pair is shared by FOUR lanes that
+// each own a quarter of the head's channels (partial dot products combined with two DPP quad exchanges), so a workgroup
+// covers 256 / (4 heads) tokens (16 at 4 heads) and a sample is spread over 4x as many workgroups - the 64-token form ran
+// one workgroup per CU, one wave per SIMD, and was latency-bound end to end.  The column phase (dK, dV) uses every thread
+// of the block (blockDim = inner rounded up to a wave when inner > 256) and reads its coefficients as float4.
+// Requires d % 16 == 0 and 256 % (4 heads) == 0.
+static __global__ void __launch_bounds__(512) attn_bwd_q4_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                          const float* __restrict__ v, int ldv, const float* __restrict__ dout,
+                                                          int ldo, int heads, int nq, int nk, int d, float scale,
+                                                          float* __restrict__ dq, int lddq, float* __restrict__ dkv_part,
+                                                          int tpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int inner = heads * d;
+    float* s_k = reinterpret_cast<float*>(smem);   // [nk][inner]
+    float* s_v = s_k + nk * inner;                 // [nk][inner]
+    float* s_ds = s_v + nk * inner;                // [tpw][heads][NKB]
+    float* s_p = s_ds + tpw * heads * NKB;         // [tpw][heads][NKB]
+    const int b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int i4 = inner >> 2;
+    const int tok0 = blockIdx.x * tpw, ntok = min(tpw, nq - tok0);
+    for (int e = tid; e < nk * i4; e += nthr) {
+        const int j = e / i4, c = (e - j * i4) * 4;
+        *reinterpret_cast<float4*>(s_k + j * inner + c) = *reinterpret_cast<const float4*>(k + ((long)b * nk + j) * ldk + c);
+        *reinterpret_cast<float4*>(s_v + j * inner + c) = *reinterpret_cast<const float4*>(v + ((long)b * nk + j) * ldv + c);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int qt = tid & 3, h = (tid >> 2) % heads, tl = tid / (4 * heads);
+        const bool act = tl < ntok;
+        const int dq4 = d >> 4;                    // float4 per quarter
+        const int coff = h * d + qt * (d >> 2);    // first channel of this lane
+        const long row = (long)b * nq + tok0 + (act ? tl : 0);
+        float p[NKB], dp[NKB];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) p[j] = dp[j] = 0.f;
+        const float* qr = q + row * ldq + coff;
+        const float* dor = dout + row * ldo + coff;
+#pragma unroll 1
+        for (int c = 0; c < dq4; ++c) {
+            const float4 qv = *reinterpret_cast<const float4*>(qr + c * 4);
+            const float4 gv = *reinterpret_cast<const float4*>(dor + c * 4);
+#pragma unroll
+            for (int j = 0; j < NKB; ++j)
+                if (j < nk) {
+                    const float4 kv = *reinterpret_cast<const float4*>(s_k + j * inner + coff + c * 4);
+                    const float4 vv = *reinterpret_cast<const float4*>(s_v + j * inner + coff + c * 4);
+                    p[j] += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+                    dp[j] += gv.x * vv.x + gv.y * vv.y + gv.z * vv.z + gv.w * vv.w;
+                }
+        }
+        // the four quarter lanes of a (token, head) are one DPP quad: after two exchanges every lane holds the full sums
+        // (added in the same order in all four lanes, so they agree bit for bit)
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                float a0 = p[j], a1 = dp[j];
+                a0 += wd_dpp<0xB1>(a0);
+                a1 += wd_dpp<0xB1>(a1);
+                a0 += wd_dpp<0x4E>(a0);
+                a1 += wd_dpp<0x4E>(a1);
+                p[j] = a0;
+                dp[j] = a1;
+            }
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] *= scale;
+                mx = fmaxf(mx, p[j]);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] = expf(p[j] - mx);
+                sum += p[j];
+            }
+        const float inv = 1.f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                p[j] *= inv;
+                dot += p[j] * dp[j];
+            }
+        float ds[NKB];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) ds[j] = j < nk ? p[j] * (dp[j] - dot) * scale : 0.f;
+        if (act) {
+#pragma unroll 1
+            for (int c = 0; c < dq4; ++c) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < NKB; ++j)
+                    if (j < nk) {
+                        const float4 kv = *reinterpret_cast<const float4*>(s_k + j * inner + coff + c * 4);
+                        o.x += ds[j] * kv.x; o.y += ds[j] * kv.y; o.z += ds[j] * kv.z; o.w += ds[j] * kv.w;
+                    }
+                *reinterpret_cast<float4*>(dq + row * lddq + coff + c * 4) = o;
+            }
+        }
+        if (qt == 0 && tl < tpw) {
+#pragma unroll
+            for (int j4 = 0; j4 < NKB / 4; ++j4) {
+                const int j = j4 * 4;
+                const float z = act ? 1.f : 0.f;
+                *reinterpret_cast<float4*>(s_ds + (tl * heads + h) * NKB + j) =
+                    make_float4(z * ds[j], z * ds[j + 1], z * ds[j + 2], z * ds[j + 3]);
+                *reinterpret_cast<float4*>(s_p + (tl * heads + h) * NKB + j) =
+                    make_float4(j < nk ? z * p[j] : 0.f, j + 1 < nk ? z * p[j + 1] : 0.f, j + 2 < nk ? z * p[j + 2] : 0.f,
+                                j + 3 < nk ? z * p[j + 3] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    float* outp = dkv_part + (((long)b * gridDim.x + blockIdx.x) * 2) * nk * inner;
+    const long row0 = (long)b * nq + tok0;
+    for (int col = tid; col < inner; col += nthr) {
+        const int hh = col / d;
+        float ak[NKB], av[NKB];
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) ak[j] = av[j] = 0.f;
+        // two tokens per round: with more the compiler hoists every coefficient read of the round (255 VGPRs, one workgroup
+        // per CU); 82 VGPRs keep four workgroups resident and their loads overlap instead
+#pragma unroll 1
+        for (int t0 = 0; t0 < ntok; t0 += 2) {
+            float qv[2], gv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool okt = t0 + u < ntok;
+                qv[u] = okt ? q[(row0 + t0 + u) * ldq + col] : 0.f;
+                gv[u] = okt ? dout[(row0 + t0 + u) * ldo + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = t0 + u < ntok ? t0 + u : 0;  // (padding tokens multiply by 0)
+                const float* cds = s_ds + (t * heads + hh) * NKB;
+                const float* cp = s_p + (t * heads + hh) * NKB;
+#pragma unroll
+                for (int j4 = 0; j4 < NKB / 4; ++j4) {
+                    if (j4 * 4 < nk) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(cds + j4 * 4);
+                        const float4 p4 = *reinterpret_cast<const float4*>(cp + j4 * 4);
+                        ak[j4 * 4 + 0] += a4.x * qv[u]; ak[j4 * 4 + 1] += a4.y * qv[u];
+                        ak[j4 * 4 + 2] += a4.z * qv[u]; ak[j4 * 4 + 3] += a4.w * qv[u];
+                        av[j4 * 4 + 0] += p4.x * gv[u]; av[j4 * 4 + 1] += p4.y * gv[u];
+                        av[j4 * 4 + 2] += p4.z * gv[u]; av[j4 * 4 + 3] += p4.w * gv[u];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NKB; ++j)
+            if (j < nk) {
+                outp[((long)j * 2 + 0) * inner + col] = ak[j];
+                outp[((long)j * 2 + 1) * inner + col] = av[j];
+            }
+    }
+}
+
+static bool attn_bwd_q4_ok(int heads, int d) { return d % 16 == 0 && heads <= 64 && 256 % (4 * heads) == 0; }
+
 static int attn_bwd_tpw(int heads, int nq, int nk, int d) {
     const int inner = heads * d;
-    int tpw = 256 / heads;
+    int tpw = attn_bwd_q4_ok(heads, d) ? 256 / (4 * heads) : 256 / heads;
     if (nq < tpw) tpw = nq;
     const long floats = (long)2 * nk * inner + (long)2 * tpw * heads * NKB;
     return floats * 4 <= 150 * 1024 ? tpw : 0;
@@ -891,18 +1060,27 @@ extern "C" int wd_attention_bwd_small(const float* q, int ldq, const float* k, i
     if (tpw <= 0) return WD_EINVAL;
     const size_t smem = ((size_t)2 * nk * inner + (size_t)2 * tpw * heads * NKB) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static size_t set = 64 * 1024;
-    if (smem > set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel),
+    const bool q4 = attn_bwd_q4_ok(heads, d);
+    static size_t set = 64 * 1024, set4 = 64 * 1024;
+    if (smem > (q4 ? set4 : set)) {
+        if (hipFuncSetAttribute(q4 ? reinterpret_cast<const void*>(&attn_bwd_q4_kernel)
+                                   : reinterpret_cast<const void*>(&attn_bwd_small_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return WD_ELAUNCH;
-        set = smem;
+        (q4 ? set4 : set) = smem;
     }
     const int nwg = (nq + tpw - 1) / tpw;
     if (nwg_out) *nwg_out = nwg;
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(nwg, batch), dim3(256), smem, st, q, ldq, k, ldk, v, ldv, dout, ldo, heads,
-                       nq, nk, d, scale, dq, lddq, dkv_part, tpw);
+    if (q4) {
+        int nthr = inner > 256 ? (inner + 63) / 64 * 64 : 256;
+        if (nthr > 512) nthr = 512;
+        hipLaunchKernelGGL(attn_bwd_q4_kernel, dim3(nwg, batch), dim3(nthr), smem, st, q, ldq, k, ldk, v, ldv, dout, ldo, heads, nq,
+                           nk, d, scale, dq, lddq, dkv_part, tpw);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(nwg, batch), dim3(256), smem, st, q, ldq, k, ldk, v, ldv, dout, ldo, heads,
+                           nq, nk, d, scale, dq, lddq, dkv_part, tpw);
+    }
     return wd_check_launch();
 }
 
