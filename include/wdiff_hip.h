@@ -296,6 +296,12 @@ int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf
                  wd_bf16* t_lo, float* colpart, void* stream);
 int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate, float scale,
                      void* stream);
+/* The same finish for `n` (partials -> gradient) pairs in one launch (nseg = 1 each).  `table` is a device array of
+ * wd_colsum_entry_bytes()-sized records {const float* part; float* out; int32 nblk, c, accumulate; float scale}; max_c = the
+ * widest entry.  Entries must write distinct `out` rows.  Used by the training backward for every bias gradient at once
+ * (reference: the bias terms of loss.backward(), train.py:291). */
+int wd_colsum_entry_bytes(void);
+int wd_colsum_finish_multi(const void* table, int n, int max_c, void* stream);
 
 /* Attention backward (CrossAttention.forward unetPhosc.py:157-198, Word_Attention :696-708) for any number of keys <= 1024
  * (spatial self-attention, the 779-token PHOSC context): recomputes the

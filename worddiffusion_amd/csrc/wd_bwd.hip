@@ -220,6 +220,36 @@ __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ p
     }
 }
 
+// The same finish for a whole list of (partial sums -> parameter gradient) pairs in one launch: grid (column tiles of the widest
+// entry, entries).  The training backward defers its bias-gradient finishes to one of these at its end (they are launch-bound:
+// ~45 launches of a few microseconds each otherwise).
+struct ColRef {
+    const float* part;
+    float* out;
+    int32_t nblk, c, accumulate;
+    float scale;
+};
+__global__ void __launch_bounds__(256) colsum_multi_kernel(const ColRef* __restrict__ tab) {
+    __shared__ double red[16][17];
+    const ColRef e = tab[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= e.c) return;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    double acc = 0.0;
+    if (col < e.c)
+        for (int k = rl; k < e.nblk; k += 16) acc += (double)e.part[(long)k * e.c + col];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && col < e.c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        const float v = (float)t * e.scale;
+        float* o = e.out + col;
+        *o = e.accumulate ? *o + v : v;
+    }
+}
+
 // ---- GroupNorm (+SiLU) backward, pass 1: per (sample, chunk, channel) sums of dy and dy * xhat,
 // sums[b][chunk][2][c] (planar: row-summing it gives [d beta | d gamma])
 constexpr int GB_TOK = 32;
@@ -1190,5 +1220,15 @@ extern "C" int wd_colsum_finish(const float* part, int nblk, int c, int nseg, fl
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(colsum_stage2, dim3((c + 15) / 16, nseg), dim3(256), 0, st, part, nblk, c, nseg, out, out_ld, accumulate,
                        scale);
+    return wd_check_launch();
+}
+
+extern "C" int wd_colsum_entry_bytes() { return (int)sizeof(ColRef); }
+
+extern "C" int wd_colsum_finish_multi(const void* table, int n, int max_c, void* stream) {
+    if (!table || n <= 0 || max_c <= 0) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((max_c + 15) / 16, n), dim3(256), 0, st, reinterpret_cast<const ColRef*>(table));
     return wd_check_launch();
 }

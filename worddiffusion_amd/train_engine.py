@@ -21,6 +21,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import _native as N
@@ -62,6 +64,8 @@ class TrainEngine(UNetEngine):
         self._scr: Dict[str, torch.Tensor] = {}
         self._arena = None
         self._arena_used = 0
+        self.defer_bias_sums = os.environ.get("WDIFF_DEFER_BIAS", "1") != "0"
+        self._deferred, self._deferred_outs = [], {}
 
     def set_precision(self, mode: str):
         old = self.npass
@@ -176,6 +180,38 @@ class TrainEngine(UNetEngine):
         """All parameter gradients as one flat fp32 tensor (views of it are the ``param.grad``s)."""
         return self._arena[: self._arena_used]
 
+    def _bias_finish(self, ops, what, colpart, nblk, n, b):
+        """Bias gradient = sum over the 64-row blocks of ``colpart``: deferred to the batched launches at the end of the
+        backward list (``wd_colsum_finish_multi``).  A gradient row with several writers (the word encoder's projections run
+        once per token group in the PHOSC variant) gets one entry per writer, in successive rounds = successive launches."""
+        acc = self._pacc(b)
+        if not self.defer_bias_sums:
+            ops.append((self.lib.wd_colsum_finish, (colpart.data_ptr(), nblk, n, 1, b.data_ptr(), n, acc, 1.0), what))
+            return
+        rnd = self._deferred_outs.get(b.data_ptr(), 0)
+        if acc and rnd == 0:
+            # an earlier, non-deferred op of this backward list already wrote the row: keep program order
+            ops.append((self.lib.wd_colsum_finish, (colpart.data_ptr(), nblk, n, 1, b.data_ptr(), n, acc, 1.0), what))
+            return
+        self._deferred_outs[b.data_ptr()] = rnd + 1
+        while len(self._deferred) <= rnd:
+            self._deferred.append([])
+        self._deferred[rnd].append((colpart.data_ptr(), b.data_ptr(), nblk, n, 1 if rnd else 0, 1.0))
+
+    def _flush_deferred(self, P):
+        import struct
+        for rnd, entries in enumerate(self._deferred):
+            if not entries:
+                continue
+            rec = self.lib.wd_colsum_entry_bytes()
+            assert rec == 32, rec
+            blob = b"".join(struct.pack("<QQiiif", *e) for e in entries)
+            table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            P.keep.append(table)
+            P.bwd.append((self.lib.wd_colsum_finish_multi, (table.data_ptr(), len(entries), max(e[3] for e in entries)),
+                          f"bias gradients: deferred finishes (round {rnd})"))
+        self._deferred, self._deferred_outs = [], {}
+
     def _pacc(self, t: torch.Tensor) -> int:
         """1 if the backward list has already written this parameter-gradient buffer (shared norm2), else 0."""
         k = t.data_ptr()
@@ -254,7 +290,13 @@ class TrainEngine(UNetEngine):
         # bias / FiLM gradients come out of the same pass as per-64-row column sums whenever the segments line up
         fuse_cs = (bool(bias) or film_off is not None) and (film_off is None or hw_out % 64 == 0)
         if fuse_cs:
-            colpart = self._scratch("colpart", self._max_colpart, torch.float32)
+            if bias and self.defer_bias_sums:
+                # the bias-gradient finish of this layer runs in the one batched launch at the end of the backward list, so
+                # its partial sums need a buffer of their own
+                colpart = torch.empty((mpad // 64) * n, dtype=torch.float32, device=self.device)
+                P.keep.append(colpart)
+            else:
+                colpart = self._scratch("colpart", self._max_colpart, torch.float32)
             assert (mpad // 64) * n <= colpart.numel(), what
         if need_dx or need_dw or fuse_cs:
             # one pass over d(output): row-major planes (data gradient), transposed planes (weight gradient), column sums
@@ -299,16 +341,14 @@ class TrainEngine(UNetEngine):
                              self._dfilm.data_ptr() + 4 * film_off, self.film_total, 0)
             for b in bias:
                 if fuse_cs:
-                    ops.append((lib.wd_colsum_finish, (colpart.data_ptr(), mpad // 64, n, 1, b.data_ptr(), n, self._pacc(b), 1.0),
-                                what + ":dbias"))
+                    self._bias_finish(ops, what + ":dbias", colpart, mpad // 64, n, b)
                 else:
                     self._colsum(ops, what + ":dbias", self._dfilm.data_ptr() + 4 * film_off, self.film_total, B, n, B,
                                  b.data_ptr(), n, self._pacc(b))
         else:
             for b in bias:
                 if fuse_cs:
-                    ops.append((lib.wd_colsum_finish, (colpart.data_ptr(), mpad // 64, n, 1, b.data_ptr(), n, self._pacc(b), 1.0),
-                                what + ":dbias"))
+                    self._bias_finish(ops, what + ":dbias", colpart, mpad // 64, n, b)
                 else:
                     self._colsum(ops, what + ":dbias", dout.data_ptr(), ldd, M, n, M, b.data_ptr(), n, self._pacc(b))
 
@@ -711,6 +751,7 @@ class TrainEngine(UNetEngine):
         self._ctx_len = L
         self._tape = []
         self._pw = set()
+        self._deferred, self._deferred_outs = [], {}
         self._gn_names = {}
         dev = self.device
         mc = m.model_channels
@@ -896,6 +937,7 @@ class TrainEngine(UNetEngine):
                                    dx=[(de, cd, 0, 0, cd)], dx_rows=B * n_tok, dx_hw=n_tok)], bias=[qkv_b])
             bops.append((lib.wd_embedding_bwd, (ids.data_ptr(), i64, B * n_tok, de.data_ptr(), cd, we.embedding.weight.shape[0], cd,
                                                 dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
+        self._flush_deferred(P)
         self._tape = []
         self._tplans[key] = P
         return P
