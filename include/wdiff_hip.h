@@ -297,9 +297,10 @@ int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf
 int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate, float scale,
                      void* stream);
 /* The same finish for `n` (partials -> gradient) pairs in one launch (nseg = 1 each).  `table` is a device array of
- * wd_colsum_entry_bytes()-sized records {const float* part; float* out; int32 nblk, c, accumulate; float scale}; max_c = the
- * widest entry.  Entries must write distinct `out` rows.  Used by the training backward for every bias gradient at once
- * (reference: the bias terms of loss.backward(), train.py:291). */
+ * wd_colsum_entry_bytes()-sized records {const float* part; float* out; int32 nblk, c, ld, accumulate; float scale; int32 pad}:
+ * out[0..c) (+)= scale * sum over k < nblk of part[k * ld + col]; max_c = the widest entry.  Entries of one launch must write
+ * distinct `out` ranges.  Used by the training backward for every bias / norm-affine gradient at once (reference: those terms
+ * of loss.backward(), train.py:291). */
 int wd_colsum_entry_bytes(void);
 int wd_colsum_finish_multi(const void* table, int n, int max_c, void* stream);
 

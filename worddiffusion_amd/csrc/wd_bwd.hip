@@ -226,8 +226,9 @@ __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ p
 struct ColRef {
     const float* part;
     float* out;
-    int32_t nblk, c, accumulate;
+    int32_t nblk, c, ld, accumulate;
     float scale;
+    int32_t pad;
 };
 __global__ void __launch_bounds__(256) colsum_multi_kernel(const ColRef* __restrict__ tab) {
     __shared__ double red[16][17];
@@ -236,8 +237,19 @@ __global__ void __launch_bounds__(256) colsum_multi_kernel(const ColRef* __restr
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
     double acc = 0.0;
-    if (col < e.c)
-        for (int k = rl; k < e.nblk; k += 16) acc += (double)e.part[(long)k * e.c + col];
+    if (col < e.c) {
+        const float* p = e.part + col;
+        int k = rl;
+        for (; k + 48 < e.nblk; k += 64) {  // four rows in flight per thread; the order of the adds is fixed
+            const float v0 = p[(long)k * e.ld], v1 = p[(long)(k + 16) * e.ld], v2 = p[(long)(k + 32) * e.ld],
+                        v3 = p[(long)(k + 48) * e.ld];
+            acc += (double)v0;
+            acc += (double)v1;
+            acc += (double)v2;
+            acc += (double)v3;
+        }
+        for (; k < e.nblk; k += 16) acc += (double)p[(long)k * e.ld];
+    }
     red[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && col < e.c) {

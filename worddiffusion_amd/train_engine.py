@@ -181,22 +181,25 @@ class TrainEngine(UNetEngine):
         return self._arena[: self._arena_used]
 
     def _bias_finish(self, ops, what, colpart, nblk, n, b):
-        """Bias gradient = sum over the 64-row blocks of ``colpart``: deferred to the batched launches at the end of the
-        backward list (``wd_colsum_finish_multi``).  A gradient row with several writers (the word encoder's projections run
-        once per token group in the PHOSC variant) gets one entry per writer, in successive rounds = successive launches."""
-        acc = self._pacc(b)
-        if not self.defer_bias_sums:
-            ops.append((self.lib.wd_colsum_finish, (colpart.data_ptr(), nblk, n, 1, b.data_ptr(), n, acc, 1.0), what))
+        """Bias gradient = sum over the 64-row blocks of ``colpart``."""
+        self._param_colsum(ops, what, colpart.data_ptr(), n, nblk, n, b.data_ptr(), self._pacc(b), key=b.data_ptr())
+
+    def _param_colsum(self, ops, what, src_ptr, ld, rows, c, out_ptr, acc, key=None):
+        """out[0..c) (+)= column sums of src[rows, c] (row pitch ld) where ``out`` is a PARAMETER gradient, so nothing in the
+        backward list reads it: deferred to the batched launches at the end of the list (``wd_colsum_finish_multi``), one
+        launch per round.  A gradient with several writers (a norm shared by two attentions, the word encoder's projections
+        run once per token group in the PHOSC variant) gets one entry per writer, in successive rounds.  ``src`` must stay
+        intact until the end of the list (a plan-owned buffer, not a shared scratch)."""
+        key = out_ptr if key is None else key
+        rnd = self._deferred_outs.get(key, 0)
+        if not self.defer_bias_sums or rows > 1024 or (acc and rnd == 0):
+            # (acc and rnd == 0: an earlier, non-deferred op of this list already wrote the row - keep program order)
+            self._colsum(ops, what, src_ptr, ld, rows, c, rows, out_ptr, c, acc)
             return
-        rnd = self._deferred_outs.get(b.data_ptr(), 0)
-        if acc and rnd == 0:
-            # an earlier, non-deferred op of this backward list already wrote the row: keep program order
-            ops.append((self.lib.wd_colsum_finish, (colpart.data_ptr(), nblk, n, 1, b.data_ptr(), n, acc, 1.0), what))
-            return
-        self._deferred_outs[b.data_ptr()] = rnd + 1
+        self._deferred_outs[key] = rnd + 1
         while len(self._deferred) <= rnd:
             self._deferred.append([])
-        self._deferred[rnd].append((colpart.data_ptr(), b.data_ptr(), nblk, n, 1 if rnd else 0, 1.0))
+        self._deferred[rnd].append((src_ptr, out_ptr, rows, c, ld, 1 if (rnd or acc) else 0, 1.0, 0))
 
     def _flush_deferred(self, P):
         import struct
@@ -204,12 +207,12 @@ class TrainEngine(UNetEngine):
             if not entries:
                 continue
             rec = self.lib.wd_colsum_entry_bytes()
-            assert rec == 32, rec
-            blob = b"".join(struct.pack("<QQiiif", *e) for e in entries)
+            assert rec == 40, rec
+            blob = b"".join(struct.pack("<QQiiiifi", *e) for e in entries)
             table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
             P.keep.append(table)
             P.bwd.append((self.lib.wd_colsum_finish_multi, (table.data_ptr(), len(entries), max(e[3] for e in entries)),
-                          f"bias gradients: deferred finishes (round {rnd})"))
+                          f"parameter-gradient column sums: deferred finishes (round {rnd})"))
         self._deferred, self._deferred_outs = [], {}
 
     def _pacc(self, t: torch.Tensor) -> int:
@@ -375,13 +378,11 @@ class TrainEngine(UNetEngine):
             g, acc = self._gacc(P, s)
             ops.append((lib.wd_gn_bwd_apply, common + (g.data_ptr(), s.c, acc), what + ":apply"))
             if len(srcs) == 1:
-                self._colsum(ops, what + ":dbeta|dgamma", sums.data_ptr(), 2 * s.c, B * nb, 2 * s.c, B * nb, pair.data_ptr(),
-                             2 * s.c, accp)
+                self._param_colsum(ops, what + ":dbeta|dgamma", sums.data_ptr(), 2 * s.c, B * nb, 2 * s.c, pair.data_ptr(), accp)
             else:
-                self._colsum(ops, what + ":dbeta", sums.data_ptr(), 2 * s.c, B * nb, s.c, B * nb, dbet.data_ptr() + 4 * off,
-                             s.c, accp)
-                self._colsum(ops, what + ":dgamma", sums.data_ptr() + 4 * s.c, 2 * s.c, B * nb, s.c, B * nb,
-                             dgam.data_ptr() + 4 * off, s.c, accp)
+                self._param_colsum(ops, what + ":dbeta", sums.data_ptr(), 2 * s.c, B * nb, s.c, dbet.data_ptr() + 4 * off, accp)
+                self._param_colsum(ops, what + ":dgamma", sums.data_ptr() + 4 * s.c, 2 * s.c, B * nb, s.c,
+                                   dgam.data_ptr() + 4 * off, accp)
             off += s.c
 
     def _ln_bwd(self, P, what, x: torch.Tensor, rows, c, ln: torch.nn.LayerNorm, name, dy: torch.Tensor, dx: torch.Tensor,
@@ -393,8 +394,7 @@ class TrainEngine(UNetEngine):
         ops.append((lib.wd_layernorm_bwd, (x.data_ptr(), c, dy.data_ptr(), c, rows, c, self._w[name + ".g"].data_ptr(), 1e-5,
                                            dx.data_ptr(), c, int(acc), colpart.data_ptr()), what))
         pair = self._ppair(ln.weight, ln.bias)  # [d gamma | d beta], the order of colpart
-        self._colsum(ops, what + ":dgamma|dbeta", colpart.data_ptr(), 2 * c, nblk, 2 * c, nblk, pair.data_ptr(), 2 * c,
-                     self._pacc(pair))
+        self._param_colsum(ops, what + ":dgamma|dbeta", colpart.data_ptr(), 2 * c, nblk, 2 * c, pair.data_ptr(), self._pacc(pair))
 
     def _attn_bwd(self, P, what, q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, dO: torch.Tensor, heads, nq, nk, d, scale, dq_ptr, lddq,
                   dkv_ptr, dkv_pitch_floats):
