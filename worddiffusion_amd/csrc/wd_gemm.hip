@@ -2006,7 +2006,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
     static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
     const int ks = ks_env == 1 ? 1 : 2;
-    static const int stagger_min = getenv("WDIFF_GEMM_STAGGER_MIN") ? atoi(getenv("WDIFF_GEMM_STAGGER_MIN")) : 16;
+    static const int stagger_min = getenv("WDIFF_GEMM_STAGGER_MIN") ? atoi(getenv("WDIFF_GEMM_STAGGER_MIN")) : 10;
     static const bool stagger = getenv("WDIFF_GEMM_STAGGER") ? atoi(getenv("WDIFF_GEMM_STAGGER")) != 0 : true;
     static const bool m16 = getenv("WDIFF_GEMM_M16") ? atoi(getenv("WDIFF_GEMM_M16")) != 0 : true;
     static const bool pp = getenv("WDIFF_GEMM_PP") ? atoi(getenv("WDIFF_GEMM_PP")) != 0 : false;  // measured: no gain
