@@ -148,6 +148,33 @@ def cpu_baseline(threads):
                        f"{dt:.3f} s/step, extrapolated to {T - 1} steps", s_per_step=dt)
 
 
+def vae_leg(dev, precision, B):
+    """the decode that follows the 999 steps (train.py:239-247) - SD-v1.5 AutoencoderKL decoder, synthetic
+    weights, [B,4,8,32] latents -> [B,3,64,256] images.  An extra object beside the headline (the headline metric excludes the
+    VAE decode by definition, section 8d)."""
+    from worddiffusion_amd.synthetic import fill_module_
+    from worddiffusion_amd.vae import AutoencoderKL
+    vae = AutoencoderKL()
+    fill_module_(vae, 0)
+    vae = vae.to(dev).eval()
+    vae.set_precision(precision)
+    z = torch.randn(B, 4, 8, 32, device=dev) / 0.18215
+    for _ in range(2):
+        img = vae.decode(z).sample
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        img = vae.decode(z).sample
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return dict(workload="AutoencoderKL decode of the batch ([B,4,8,32] -> [B,3,64,256]), SD-v1.5 decoder, synthetic weights",
+                ms_per_batch=ms, images_per_sec=B * 1e3 / ms, output_finite=bool(torch.isfinite(img).all().item()),
+                share_of_a_sampling_call=None)
+
+
 def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
     """BASELINE configs[2]/[3]: the train.py batch loop (noise_images -> UNet -> MSE -> backward -> AdamW -> EMA) on the same
     model and latent shape as the headline, synthetic batch resident in HBM, one gradient all-reduce per step when world > 1.
@@ -230,6 +257,7 @@ def main():
                          "(configs[4] model: 779-token context, 256-token self-attention), reported as an extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode extra (section 8f-2)")
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="also time this many train.py-style steps (0 = skip; default: 30 on one GPU, 0 on several - the "
                          "multi-GPU run is the scaling measurement of the headline metric, pass a count to add the data-parallel "
@@ -329,6 +357,17 @@ def main():
         except Exception as e:  # the extra leg must never cost the headline line
             train = dict(error=f"{type(e).__name__}: {e}")
 
+    vae = None
+    if rank == 0 and world == 1 and not a.no_vae and a.variant == "base":
+        try:
+            if train is None:
+                del runner
+            torch.cuda.empty_cache()
+            vae = vae_leg(dev, a.precision, B)
+            vae["share_of_a_sampling_call"] = vae["ms_per_batch"] / (ms_per_step * (T - 1) + vae["ms_per_batch"])
+        except Exception as e:
+            vae = dict(error=f"{type(e).__name__}: {e}")
+
     if rank == 0:
         value = world * B * 1e3 / (ms_per_step * (T - 1))
         line = dict(metric="denoised 64x256 word images/sec (1000-step DDPM), whole job", value=value, unit="images/s",
@@ -343,7 +382,7 @@ def main():
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
                                 images_per_sec_per_gpu=value / world, output_finite=finite,
                                 per_call_setup_ms=setup_ms),
-                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra, train_step=train)
+                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra, train_step=train, vae_decode=vae)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -211,3 +211,49 @@ def test_phosc_descriptors_match_reference_golden(golden_dir, tmp_path):
     assert len(phosc_vector("Stop", {k: i for i, k in enumerate(str(x) for x in g["eng:letters"])}, g["eng:table"])) == 769
     with pytest.raises(KeyError):
         phos_vector("é", {"a": 0}, np.zeros((1, 11), dtype=int))
+
+
+def test_vae_decoder_state_dict_layout(tmp_path):
+    """The decoder container has the diffusers AutoencoderKL keys / shapes of the SD-v1.5 VAE (49,490,179 decoder parameters +
+    the 1x1 post_quant_conv), accepts the pre-0.14 attention names, ignores the encoder half, and round-trips through a local
+    diffusers-layout directory (safetensors)."""
+    import json
+    from safetensors.torch import save_file
+    from worddiffusion_amd.vae import AutoencoderKL
+    m = AutoencoderKL()
+    sd = m.state_dict()
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("decoder.")) == 49_490_179
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("post_quant_conv.")) == 20
+    expect = {"decoder.conv_in.weight": (512, 4, 3, 3), "decoder.mid_block.attentions.0.to_q.weight": (512, 512),
+              "decoder.mid_block.attentions.0.to_out.0.bias": (512,), "decoder.up_blocks.0.upsamplers.0.conv.weight": (512, 512, 3, 3),
+              "decoder.up_blocks.2.resnets.0.conv_shortcut.weight": (256, 512, 1, 1),
+              "decoder.up_blocks.3.resnets.0.conv1.weight": (128, 256, 3, 3), "decoder.up_blocks.3.resnets.2.norm2.weight": (128,),
+              "decoder.conv_norm_out.weight": (128,), "decoder.conv_out.weight": (3, 128, 3, 3), "post_quant_conv.weight": (4, 4, 1, 1)}
+    for k, shp in expect.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert not any("upsamplers" in k for k in sd if k.startswith("decoder.up_blocks.3."))
+    # old attention naming + encoder entries in a checkpoint
+    old = {}
+    for k, v in sd.items():
+        for new_n, old_n in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            if f"attentions.0.{new_n}." in k:
+                k = k.replace(f"attentions.0.{new_n}.", f"attentions.0.{old_n}.")
+                if v.dim() == 2:
+                    v = v[:, :, None, None]  # some exports keep the projections as 1x1 convolutions
+        old[k] = torch.full_like(v, 0.5)
+    old["encoder.conv_in.weight"] = torch.zeros(128, 3, 3, 3)
+    old["quant_conv.weight"] = torch.zeros(8, 8, 1, 1)
+    m.load_state_dict(old)
+    assert all(float(v.min()) == 0.5 == float(v.max()) for v in m.state_dict().values())
+    d = tmp_path / "sd" / "vae"
+    d.mkdir(parents=True)
+    small = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1)
+    save_file({k: v.contiguous() for k, v in small.state_dict().items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"block_out_channels": [64, 128], "layers_per_block": 1, "latent_channels": 4,
+                                               "_class_name": "AutoencoderKL", "sample_size": 512}))
+    back = AutoencoderKL.from_pretrained(str(tmp_path / "sd"), subfolder="vae")
+    assert back.config.block_out_channels == (64, 128)
+    for k, v in small.state_dict().items():
+        assert torch.equal(v, back.state_dict()[k])
+    with pytest.raises(Exception):
+        back.decode(torch.zeros(1, 4, 4, 8))  # no CPU fallback

@@ -27,6 +27,9 @@ SHAPES = {
     "ff2": (8, 32, 1280, 320, "lin"),
     "lin4x16": (4, 16, 320, 320, "lin"),
     "temb": (1, 1, 1280, 1280, "lin"),
+    "lin_k64": (8, 32, 64, 320, "lin"),      # one stage: the fixed cost of a launch (prologue + epilogue)
+    "lin_k128": (8, 32, 128, 320, "lin"),
+    "conv_k576": (8, 32, 64, 320, "conv3"),  # nine one-chunk taps
 }
 
 

@@ -2,5 +2,6 @@
 from .unet import UNetModel
 from .unetPhosc import UNetModelPhosc
 from .diffusion import EMA, Diffusion, label_padding
+from .vae import AutoencoderKL
 
-__all__ = ["UNetModel", "UNetModelPhosc", "Diffusion", "EMA", "label_padding"]
+__all__ = ["UNetModel", "UNetModelPhosc", "Diffusion", "EMA", "label_padding", "AutoencoderKL"]

@@ -132,6 +132,9 @@ def main(argv=None):
     ap.add_argument("--phosc", type=int, default=0)
     ap.add_argument("--skip_steps", type=int, default=0, help="1: regenerateFromtrain2.py's step-skipping sampler")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--stable_dif_path", default=None,
+                    help="local Stable-Diffusion checkout in diffusers layout (its vae/ subfolder is read; train.py:415): with it "
+                         "the rows are decoded and written as PNGs, without it as latents (.npy)")
     a = ap.parse_args(argv)
     rank, world, local = env_rank_world()
     dev = f"cuda:{local}"
@@ -149,7 +152,11 @@ def main(argv=None):
                                         weights_only=True))
     ema_model = copy.deepcopy(unet).eval().requires_grad_(False)
     diffusion = Diffusion(noise_steps=a.noise_steps, img_size=(64, 256), args=args)
-    start, res = regenerate(ema_model, diffusion, rows, wr, args, vae=None, batch=a.batch_size,
+    vae = None
+    if a.stable_dif_path:
+        from .vae import AutoencoderKL
+        vae = AutoencoderKL.from_pretrained(a.stable_dif_path, subfolder="vae").to(dev)
+    start, res = regenerate(ema_model, diffusion, rows, wr, args, vae=vae, batch=a.batch_size,
                             out_dir=os.path.join(a.save_path, "images"), seed=a.seed, skip_steps=bool(a.skip_steps))
     print(f"[rank {rank}/{world}] rows {start}..{start + len(res)} of {len(rows)} written to {a.save_path}/images")
 

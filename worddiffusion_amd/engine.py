@@ -444,7 +444,7 @@ class UNetEngine:
         with torch.no_grad():
             for name, meta in self._w3_meta.items():
                 self._w3[name].copy_(slab_order(self._w[name], *meta))
-            if "freqs" not in self._w:
+            if "freqs" not in self._w and hasattr(self.model, "word_emb"):  # (the VAE decoder engine has neither)
                 half = self.model.model_channels // 2
                 freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
                 self._w["freqs"] = freqs.to(dev)
@@ -622,7 +622,7 @@ class UNetEngine:
                             out_ld=cout, want_stats=True)
         return Act(out, cout, h, w, g2._stats)
 
-    def _resample(self, P, name, mod, x: Act, mode: str) -> Act:
+    def _resample(self, P, name, mod, x: Act, mode: str, tile: int = 0) -> Act:
         ops = P.step
         B = self._B
         tab, ho, wo = self._table(x.h, x.w, mode)
@@ -631,7 +631,7 @@ class UNetEngine:
                                         pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
         out = self._f32(P, B * ho * wo, mod.cout)
         gg = self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
-                        bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True)
+                        bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True, tile=tile)
         return Act(out, mod.cout, ho, wo, gg._stats)
 
     def _attention(self, ops, what, q, ldq, k, ldk, v, ldv, heads, nq, nk, d, scale, out_pl, out_f32=None,
