@@ -106,6 +106,9 @@ int wd_gemm(const wd_gemm_args* args, void* stream);
  * nchunk = wd_gn_nchunk(hw).  (wd_gemm can produce the same array in its epilogue: wd_gemm_args.stat_part.) */
 int wd_gn_nchunk(int hw);
 int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, double* part, void* stream);
+/* part[batch][nchunk][ngroups][2] -> out[batch][1][ngroups][2] (fixed-order sum over the chunks): lets wd_gn_apply run with
+ * nchunk = 1 where a sample has many chunks (every workgroup of wd_gn_apply folds the chunks itself otherwise). */
+int wd_gn_fold_chunks(const double* part, int batch, int nchunk, int ngroups, double* out, void* stream);
 
 /* Normalise (+ optional SiLU) channels [0, c) of x with groups of cpg channels and emit split-bf16 planes
  * out[m][c_off + ch].  `part` holds nchunk partials per sample at a granularity of part_cpg channels (part_cpg | cpg: a

@@ -175,9 +175,33 @@ __global__ void split_kernel(const float* __restrict__ x, int ld, int rows, int 
     }
 }
 
+// part[b][nchunk][ng][2] -> out[b][1][ng][2]: the chunk sums of a sample folded once (fixed order) instead of by every workgroup
+// of wd_gn_apply - at 16384 positions per sample (the VAE decoder's last level) that loop is 128 chunks long.
+// grid (batch), block 256 = 4 chunk lanes x 64 (group, sum / sum of squares) columns; ng * 2 <= 64.
+__global__ void __launch_bounds__(256) gn_fold_chunks_kernel(const double* __restrict__ part, int nchunk, int ng2,
+                                                            double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const long b = blockIdx.x;
+    double acc = 0.0;
+    if (col < ng2)
+        for (int j = lane; j < nchunk; j += 4) acc += part[(b * nchunk + j) * ng2 + col];
+    red[lane][col] = acc;
+    __syncthreads();
+    if (lane == 0 && col < ng2) out[b * ng2 + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
 }  // namespace
 
 extern "C" int wd_gn_nchunk(int hw) { return (hw + GN_TOK - 1) / GN_TOK; }
+
+extern "C" int wd_gn_fold_chunks(const double* part, int batch, int nchunk, int ngroups, double* out, void* stream) {
+    if (!part || !out || batch <= 0 || nchunk <= 0 || ngroups <= 0 || ngroups > 32) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_GNSTATS, st);
+    hipLaunchKernelGGL(gn_fold_chunks_kernel, dim3(batch), dim3(256), 0, st, part, nchunk, 2 * ngroups, out);
+    return wd_check_launch();
+}
 
 extern "C" int wd_gn_stats(const float* x, int ld, int batch, int hw, int c, int cpg, double* part, void* stream) {
     if (!x || !part || batch <= 0 || hw <= 0 || c <= 0 || cpg <= 0) return WD_EINVAL;

@@ -580,6 +580,14 @@ class UNetEngine:
         for s in srcs:
             part, nchunk, pc = s.stats
             assert cpg % pc == 0, (what, cpg, pc)
+            if nchunk > 8:
+                # many chunks per sample (large images): fold them once here, not in every workgroup of wd_gn_apply
+                ngs = s.c // pc
+                folded = torch.empty((B, 1, ngs, 2), dtype=torch.float64, device=self.device)
+                P.keep.append(folded)
+                ops.append((self.lib.wd_gn_fold_chunks, (part.data_ptr(), B, nchunk, ngs, folded.data_ptr()), what + ":fold chunks"))
+                part, nchunk = folded, 1
+                s.stats = (part, nchunk, pc)
             ops.append((self.lib.wd_gn_apply,
                         (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(),
                          bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None,
