@@ -120,6 +120,15 @@ int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, const
                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int c_off,
                 wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);
 
+/* out[b][o][y][x] (NCHW, o < oc <= 4) = Conv3x3(SiLU?(GroupNorm(x)))[o] + bias[o] in one launch, fp32 VALU: the UNet's last layer
+ * (GroupNorm32, SiLU, conv 320 -> 4; unet.py:1453-1458) and any other few-output-channel 3x3 (pad 1, stride 1).
+ * x: token-major fp32 [batch*h*w][ld]; part / nchunk / part_cpg: GroupNorm statistics as for wd_gn_apply; weight: the
+ * parameter itself, fp32 [oc][c][3][3].  wd_gn_conv3x3_few_supported(c, w, oc): c % 64 == 0, w <= 64, oc <= 4, LDS fit. */
+int wd_gn_conv3x3_few_supported(int c, int w, int oc);
+int wd_gn_conv3x3_few(const float* x, int ld, int batch, int h, int w, int c, int cpg, const double* part, int nchunk, int part_cpg,
+                      const float* gamma, const float* beta, float eps, int silu, const float* weight, const float* bias, int oc,
+                      float* out, void* stream);
+
 /* nn.LayerNorm(c, eps) over the last dim (unet.py:314-316), one row per token -> planes. */
 int wd_layernorm(const float* x, int ld, int rows, int c, const float* gamma, const float* beta, float eps,
                  wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);

@@ -633,3 +633,31 @@ def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit):
     # same result as the generic kernel up to summation order
     out0, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), ksplit=ksplit)
     assert max_rel(out.cpu(), out0.cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("B,h,w,c,oc,silu", [(3, 5, 7, 64, 4, 1), (2, 8, 32, 320, 4, 1), (2, 4, 40, 128, 3, 1), (1, 3, 64, 64, 1, 0)])
+def test_gn_silu_conv3x3_few_output_channels(B, h, w, c, oc, silu):
+    """wd_gn_conv3x3_few (the UNet's last layer in one fp32 launch) vs GroupNorm -> SiLU -> conv2d in fp64; statistics both from
+    wd_gn_stats chunks and narrow / wide images (32 and 64 pixel lanes)."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B + h + w + c)
+    x = torch.randn(B, c, h, w, generator=g) * 2 + 0.3
+    gam, bet = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    wt = torch.randn(oc, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    bias = torch.randn(oc, generator=g)
+    y = F.group_norm(x.double(), 32, gam.double(), bet.double(), eps=1e-5)
+    y = F.silu(y) if silu else y
+    ref = F.conv2d(y, wt.double(), bias.double(), padding=1)
+    hw = h * w
+    tok = x.permute(0, 2, 3, 1).reshape(B * hw, c).contiguous().to(DEV)
+    nchunk = lib.wd_gn_nchunk(hw)
+    part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+    N.check(lib.wd_gn_stats(tok.data_ptr(), c, B, hw, c, c // 32, part.data_ptr(), _st()), "stats")
+    out = torch.full((B, oc, h, w), float("nan"), device=DEV)
+    assert lib.wd_gn_conv3x3_few_supported(c, w, oc)
+    gd, bd, wd, bid = gam.to(DEV), bet.to(DEV), wt.to(DEV), bias.to(DEV)
+    N.check(lib.wd_gn_conv3x3_few(tok.data_ptr(), c, B, h, w, c, c // 32, part.data_ptr(), nchunk, c // 32, gd.data_ptr(),
+                                  bd.data_ptr(), 1e-5, silu, wd.data_ptr(), bid.data_ptr(), oc, out.data_ptr(), _st()), "gn_conv")
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), ref) < 2e-6
+    assert not lib.wd_gn_conv3x3_few_supported(c, 65, oc) and not lib.wd_gn_conv3x3_few_supported(c, w, 5)

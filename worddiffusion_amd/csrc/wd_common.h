@@ -64,7 +64,9 @@ __device__ __forceinline__ void wd_split4(const float4 v, uint2& hi, uint2& lo) 
                     wd_pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)));
 }
 
-__device__ __forceinline__ float wd_silu(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: 1 ulp each) - the IEEE expf + division form costs
+// ~25 VALU instructions per element, which made the SiLU the largest part of the GroupNorm-apply kernels' arithmetic
+__device__ __forceinline__ float wd_silu(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
 __device__ __forceinline__ float wd_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // 64-lane reductions on the DPP path (quad permutes + row rotates inside each row of 16 lanes, then one v_readlane per

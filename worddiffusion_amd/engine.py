@@ -268,6 +268,7 @@ class UNetEngine:
         # row-shared-taps convolution kernel (29 % fewer DMA pieces, but measured 15 % slower than the generic kernel so far)
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
+        self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
@@ -389,6 +390,7 @@ class UNetEngine:
         R.vector("out.gn.b", m.out[0].bias)
         R.matrix("out.w", m.out[2].out_channels, 9 * m.out[2].in_channels).fwd(m.out[2].weight)
         R.vector("out.b", m.out[2].bias)
+        R.vector("out.w.f32", m.out[2].weight)  # the fused GroupNorm + SiLU + 3x3 kernel reads the parameter layout itself
         return R
 
     def _walk(self):
@@ -915,16 +917,31 @@ class UNetEngine:
         cur = run_layers("mid", m.middle_block, cur)
         for i, blk in enumerate(m.output_blocks):
             cur = run_layers(f"out{i}", blk, cur, extra=hs.pop())
-        g, _ = self._gn(P, step, "out.gn", [cur], "out.gn", 1e-5, True)
-        tab, _, _ = self._table(cur.h, cur.w, "same")
         oc = m.out_channels
-        otok = self._f32(P, B * cur.h * cur.w, oc)
-        self._gemm(step, "out.conv", [self._src(g, cur.c, 9, tab, cur.h * cur.w)], "out.w", B * cur.h * cur.w,
-                   cur.h * cur.w, bias=self._w["out.b"], out_f32=otok, out_ld=oc)
         P.out = torch.empty((B, oc, cur.h, cur.w), dtype=torch.float32, device=dev)
-        step.append((lib.wd_tokens_to_nchw, (otok.data_ptr(), oc, B, oc, cur.h * cur.w, P.out.data_ptr()),
-                     "tokens_to_nchw"))
-        P.out_tok = otok
+        if self.fuse_out and lib.wd_gn_conv3x3_few_supported(cur.c, cur.w, oc) and cur.c % 32 == 0:
+            # GroupNorm + SiLU + the 320 -> 4 convolution + NCHW in one fp32 launch (as a GEMM it fills 4 of 64 tile columns)
+            if cur.stats is None:
+                nchunk = lib.wd_gn_nchunk(cur.h * cur.w)
+                part = torch.empty((B, nchunk, 32, 2), dtype=torch.float64, device=dev)
+                P.keep.append(part)
+                step.append((lib.wd_gn_stats, (cur.t.data_ptr(), cur.c, B, cur.h * cur.w, cur.c, cur.c // 32, part.data_ptr()),
+                             "out.gn:stats"))
+                cur.stats = (part, nchunk, cur.c // 32)
+            part, nchunk, pc = cur.stats
+            step.append((lib.wd_gn_conv3x3_few,
+                         (cur.t.data_ptr(), cur.c, B, cur.h, cur.w, cur.c, cur.c // 32, part.data_ptr(), nchunk, pc,
+                          self._w["out.gn.g"].data_ptr(), self._w["out.gn.b"].data_ptr(), 1e-5, 1,
+                          self._w["out.w.f32"].data_ptr(), self._w["out.b"].data_ptr(), oc, P.out.data_ptr()),
+                         "out: GroupNorm + SiLU + conv3x3 -> NCHW"))
+        else:
+            g, _ = self._gn(P, step, "out.gn", [cur], "out.gn", 1e-5, True)
+            tab, _, _ = self._table(cur.h, cur.w, "same")
+            otok = self._f32(P, B * cur.h * cur.w, oc)
+            self._gemm(step, "out.conv", [self._src(g, cur.c, 9, tab, cur.h * cur.w)], "out.w", B * cur.h * cur.w,
+                       cur.h * cur.w, bias=self._w["out.b"], out_f32=otok, out_ld=oc)
+            step.append((lib.wd_tokens_to_nchw, (otok.data_ptr(), oc, B, oc, cur.h * cur.w, P.out.data_ptr()),
+                         "tokens_to_nchw"))
         self._plans[key] = P
         return P
 
