@@ -18,8 +18,8 @@ __device__ __forceinline__ float silu_grad(float y) {  // d silu(y) / dy
     return s * (1.0f + y * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_grad(float g) {  // d gelu_erf(g) / dg
-    const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
-    return cdf + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+    const float cdf = 0.5f * (1.0f + wd_erf(g * 0.70710678118654752440f));
+    return cdf + g * 0.39894228040143267794f * __expf(-0.5f * g * g);
 }
 
 // ---- transpose: out[(t*C + c)][m] = in[src(m, t)][c]   (64 x 64 tiles through LDS; src = gather table or identity)

@@ -67,7 +67,17 @@ __device__ __forceinline__ void wd_split4(const float4 v, uint2& hi, uint2& lo) 
 // x * sigmoid(x) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: 1 ulp each) - the IEEE expf + division form costs
 // ~25 VALU instructions per element, which made the SiLU the largest part of the GroupNorm-apply kernels' arithmetic
 __device__ __forceinline__ float wd_silu(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
-__device__ __forceinline__ float wd_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (unet.py:136 F.gelu default).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of an fp32 ulp
+// of 1) on the hardware rcp / exp units: about a third of the instructions of libm's erff, which made this the largest
+// part of the GEGLU epilogue's arithmetic (40 gate values per thread and tile).
+__device__ __forceinline__ float wd_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __fdividef(1.0f, 1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float wd_gelu_erf(float x) { return 0.5f * x * (1.0f + wd_erf(x * 0.70710678118654752440f)); }
 
 // 64-lane reductions on the DPP path (quad permutes + row rotates inside each row of 16 lanes, then one v_readlane per
 // row): ~10 VALU-rate instructions instead of six dependent ds_bpermute round trips through the LDS crossbar.

@@ -81,6 +81,11 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
         const int rl = tid / oc4, c = (tid - rl * oc4) * 4;
         const int no = no0 + c;
         const int rps = BM > a.hw_out ? a.hw_out : BM;  // rows of one sample inside this panel
+        // (with statistics rps is BM or a divisor of it - a power of two - so row / rps is a shift; the FiLM row of m needs m /
+        // hw_out: a shift too for power-of-two images, a division otherwise.  A run-time integer division is ~25 instructions,
+        // more than the rest of a row's work.)
+        const int rps_sh = 31 - __clz(rps);
+        const int hw_sh = (a.hw_out & (a.hw_out - 1)) == 0 ? 31 - __clz(a.hw_out) : -1;
         float* scr = ep + BM * LDE;               // statistics scratch [sample][row lane][BN][2]
         float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
         int cur_s = 0;
@@ -104,7 +109,8 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
                     v.x += bx.x; v.y += bx.y; v.z += bx.z; v.w += bx.w;
                 }
                 if (a.rowvec) {
-                    const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)(m / a.hw_out) * a.rowvec_ld + no);
+                    const int bi = hw_sh >= 0 ? m >> hw_sh : m / a.hw_out;
+                    const float4 q = *reinterpret_cast<const float4*>(a.rowvec + (long)bi * a.rowvec_ld + no);
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
                 if (a.resid) {
@@ -116,7 +122,7 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
                     v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
                 }
                 if (stats) {
-                    const int sidx2 = row / rps;
+                    const int sidx2 = row >> rps_sh;
                     if (sidx2 != cur_s) {  // rows ascend: flush the finished sample's column sums
                         float* o = scr + ((cur_s * nrl + rl) * BN + c) * 2;
                         *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
