@@ -417,12 +417,13 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
         const float* pr = sS + t * SP + h * L;
         float mx = -3.4e38f;
         for (int j = 0; j < L; ++j) mx = fmaxf(mx, pr[j]);
+        // (hardware exp2: this phase is serial for the workgroup - one wave per SIMD - so its instruction count is latency)
         float sum = 0.f;
-        for (int j = 0; j < L; ++j) sum += expf(pr[j] - mx);
-        const float inv = 1.f / sum;
+        for (int j = 0; j < L; ++j) sum += __expf(pr[j] - mx);
+        const float inv = __fdividef(1.f, sum);
         for (int j = 0; j < L; ++j) {
             uint32_t hi, lo;
-            wd_split1(expf(pr[j] - mx) * inv, hi, lo);
+            wd_split1(__expf(pr[j] - mx) * inv, hi, lo);
             sP[(long)t * PP + h * L + j] = (wd_bf16)hi;
             sP[(long)(XT + t) * PP + h * L + j] = (wd_bf16)lo;
         }
