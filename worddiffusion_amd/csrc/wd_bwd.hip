@@ -13,8 +13,8 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_grad(float y) {  // d silu(y) / dy
-    const float s = 1.0f / (1.0f + expf(-y));
+__device__ __forceinline__ float silu_grad(float y) {  // d silu(y) / dy  (hardware exp / rcp, as wd_silu)
+    const float s = __fdividef(1.0f, 1.0f + __expf(-y));
     return s * (1.0f + y * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_grad(float g) {  // d gelu_erf(g) / dg
@@ -373,6 +373,42 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int ld, const f
     __syncthreads();
     const int c4 = c >> 2;
     const int t0 = blockIdx.x * GA_TOK, nt = min(GA_TOK, hw - t0);
+    if (c4 <= (int)blockDim.x) {
+        // thread = (token lane, channel quad): the quad is fixed, so the group lookups (integer divisions by a run-time cpg) and
+        // the per-channel constants are set up once per thread instead of once per element
+        const int rpp = blockDim.x / c4;
+        const int tl = threadIdx.x / c4, cx = (threadIdx.x - tl * c4) * 4;
+        if (tl >= rpp) return;
+        float mean[4], rstd[4], m1[4], m2[4], gam[4], bet[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (cx + k) / cpg;
+            mean[k] = s_mean[g]; rstd[k] = s_rstd[g]; m1[k] = s_m1[g]; m2[k] = s_m2[g];
+            gam[k] = gamma[c_off + cx + k]; bet[k] = beta[c_off + cx + k];
+        }
+        for (int t = tl; t < nt; t += rpp) {
+            const long row = (long)b * hw + t0 + t;
+            const float4 xv = *reinterpret_cast<const float4*>(x + row * ld + cx);
+            const float4 dv = *reinterpret_cast<const float4*>(dz + row * dz_ld + dz_off + cx);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds4[4] = {dv.x, dv.y, dv.z, dv.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xs[k] - mean[k]) * rstd[k];
+                float dy = ds4[k];
+                if (silu) dy *= silu_grad(gam[k] * xh + bet[k]);
+                o[k] = rstd[k] * (gam[k] * dy - m1[k] - xh * m2[k]);
+            }
+            float4* op = reinterpret_cast<float4*>(dx + row * dx_ld + cx);
+            float4 r = make_float4(o[0], o[1], o[2], o[3]);
+            if (accumulate) {
+                const float4 old = *op;
+                r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+            }
+            *op = r;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < nt * c4; i += blockDim.x) {
         const int t = i / c4, cx = (i - t * c4) * 4;
         const long row = (long)b * hw + t0 + t;
