@@ -45,7 +45,7 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int
 }
 
 // grid (ceil(hw / TOK_PER_WG), batch), block 256.  One float4 (4 channels) per thread per step.
-constexpr int AP_TOK = 16;
+constexpr int AP_TOK = 8;
 __global__ void gn_apply_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int nchunk, int part_cpg,
                                 const double* __restrict__ part, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, wd_bf16* __restrict__ out_hi,
