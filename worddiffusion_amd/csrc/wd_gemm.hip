@@ -474,6 +474,7 @@ __device__ __forceinline__ int lds_off2(int row, int ch) { return row * 128 + ((
 //         fragments per wave and stage - the loop is LDS-port bound (per-stage stamps: tools/gemm_bench.py --stamps).
 template <int BM, int BN, int NPASS, int KS, bool PP = false, bool M16 = false>
 __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource type and builtins exist in the device pass only)
     static_assert(!M16 || (BM == 128 && BN == 160 && KS == 2 && !PP), "M16 is the 128x160 KS=2 kernel");
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int NW = 4 * KS;
@@ -542,16 +543,23 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         const int row = (wave + NW * i) * 8 + lrow;
         a_sw[i] = (lpos ^ ((row >> 1) & 7)) * 8;  // source chunk (in elements) that lands at position lpos
     }
-    long b_off[B_INS];
-    bool b_ok[B_INS];
+    // Operands are fetched with buffer_load ... lds: a buffer resource per plane in SGPRs, a per-lane 32-bit byte offset that
+    // only changes when the tap does, and the stage's position (channel chunk / K step) in the scalar offset - no per-stage
+    // vector address arithmetic at all.  Padding and out-of-range rows carry an offset beyond num_records: the hardware
+    // returns zeros for them (raw buffer range check on the vector offset), which replaces the zero-line select.
+    // (wd_gemm() rejects operands whose plane does not fit 31-bit byte offsets.)
+    constexpr uint32_t WD_OOB = 0x80000000u;
+    auto make_srd = [](const wd_bf16* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<wd_bf16*>(p), 0, 0x7FFFFFF0, 0x00020000);
+    };
+    uint32_t b_voff[B_INS];
 #pragma unroll
     for (int i = 0; i < B_INS; ++i) {
         const int row = (wave + NW * i) * 8 + lrow;
         const int n = n0 + row;
-        b_ok[i] = (row < BN) && (n < a.n);
-        b_off[i] = (long)n * a.ktot + (lpos ^ ((row >> 1) & 7)) * 8;
+        b_voff[i] = ((row < BN) && (n < a.n)) ? (uint32_t)(((long)n * a.ktot + (lpos ^ ((row >> 1) & 7)) * 8) * 2) : WD_OOB;
     }
-    const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
+    const __amdgpu_buffer_rsrc_t srd_w_hi = make_srd(a.w_hi), srd_w_lo = make_srd(a.w_lo ? a.w_lo : a.w_hi);
 
     const int nk_all = a.ktot / BK2;
     const int k_begin = (int)((long)nk_all * sidx / a.ksplit), k_end = (int)((long)nk_all * (sidx + 1) / a.ksplit);
@@ -574,7 +582,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
             cur_nt = a.src[1].ntaps;
         }
     }
-    long a_off[A_INS];
+    __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(cur_hi), srd_a_lo = make_srd(cur_lo ? cur_lo : cur_hi);
+    uint32_t a_voff[A_INS];  // byte offset of this lane's chunk of its source row, WD_OOB = zero row
 
     auto locate = [&]() {
 #pragma unroll
@@ -585,54 +594,59 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 if (s == 0) r = s_tab[tap * BM + row];
                 else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
             }
-            a_off[i] = r >= 0 ? (long)r * cur_ld + a_sw[i] : -1;
+            a_voff[i] = r >= 0 ? (uint32_t)r * (uint32_t)(cur_ld * 2) + (uint32_t)(a_sw[i] * 2) : WD_OOB;
         }
     };
     locate();
 
-    // One stage = NSLOT DMA pieces for this wave (A hi/lo pieces first, then W hi/lo).  The addresses of the next stage
-    // are computed up front (prep), the global_load_lds themselves are issued one by one BETWEEN the MFMA groups of the
-    // current stage (fire), so that DMA issue hides in the MFMA pipe's shadow instead of preceding it as a burst.
+    // One stage = NSLOT DMA pieces for this wave (A hi/lo pieces first, then W hi/lo).  What the next stage needs is captured
+    // up front (prep: offsets, scalar offsets, the A resources - advance() may move on to the next tap / source before the
+    // pieces are issued), the loads themselves are issued one by one BETWEEN the MFMA groups of the current stage (fire), so
+    // that DMA issue hides in the MFMA pipe's shadow instead of preceding it as a burst.
     constexpr int NSLOT = NPL * (A_INS + B_INS);
-    const wd_bf16* pp[NSLOT];   // per-lane source pointer of each piece (zero line for padding / out-of-range rows)
+    uint32_t pva[A_INS];        // captured a_voff of the prepared stage
+    int soff_a = 0, soff_b = 0;  // captured scalar byte offsets (channel chunk of A, K step of W)
+    __amdgpu_buffer_rsrc_t fa_hi = srd_a_hi, fa_lo = srd_a_lo;
     int pdst[NSLOT];            // wave-uniform LDS byte offset inside the stage, < 0: this wave has no such piece
     auto prep = [&](int kit) {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
             const int piece = wave + NW * i;
+            pva[i] = a_voff[i];
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                const int sl = i * NPL + p;
-                pdst[sl] = piece < A_PIECES ? p * A_PL + piece * 1024 : -1;
-                pp[sl] = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK2 : zline;
-            }
+            for (int p = 0; p < NPL; ++p) pdst[i * NPL + p] = piece < A_PIECES ? p * A_PL + piece * 1024 : -1;
         }
 #pragma unroll
         for (int i = 0; i < B_INS; ++i) {
             const int piece = wave + NW * i;
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                const int sl = A_INS * NPL + i * NPL + p;
-                pdst[sl] = piece < B_PIECES ? NPL * A_PL + p * B_PL + piece * 1024 : -1;
-                pp[sl] = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK2 : zline;
-            }
+            for (int p = 0; p < NPL; ++p)
+                pdst[A_INS * NPL + i * NPL + p] = piece < B_PIECES ? NPL * A_PL + p * B_PL + piece * 1024 : -1;
         }
+        soff_a = kc * BK2 * 2;
+        soff_b = kit * BK2 * 2;
+        fa_hi = srd_a_hi;
+        fa_lo = srd_a_lo;
     };
-    auto fire = [&](int sl, char* sbase) {
-        if (pdst[sl] >= 0)
-            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)pp[sl], (wd_lds_ptr)(sbase + pdst[sl]), 16, 0, 0);
+    auto fire = [&](int sl, char* sbase) {  // sl is a compile-time constant at every call site (unrolled loops)
+        if (pdst[sl] < 0) return;
+        const int p = sl % NPL;
+        if (sl < A_INS * NPL)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? fa_lo : fa_hi, (wd_lds_ptr)(sbase + pdst[sl]), 16, pva[sl / NPL], soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? srd_w_lo : srd_w_hi, (wd_lds_ptr)(sbase + pdst[sl]), 16,
+                                                     b_voff[(sl - A_INS * NPL) / NPL], soff_b, 0, 0);
     };
-    // address computation and issue in one go (no per-slot pointer array kept live)
+    // address computation and issue in one go (nothing captured)
     auto prep_fire_all = [&](int kit, char* sbase) {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
             const int piece = wave + NW * i;
             if (piece < A_PIECES) {
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    const wd_bf16* src = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK2 : zline;
-                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16, 0, 0);
-                }
+                for (int p = 0; p < NPL; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? srd_a_lo : srd_a_hi, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16,
+                                                             a_voff[i], kc * BK2 * 2, 0, 0);
             }
         }
 #pragma unroll
@@ -640,11 +654,10 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
             const int piece = wave + NW * i;
             if (piece < B_PIECES) {
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    const wd_bf16* src = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK2 : zline;
-                    __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16,
-                                                     0, 0);
-                }
+                for (int p = 0; p < NPL; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? srd_w_lo : srd_w_hi,
+                                                             (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16, b_voff[i],
+                                                             kit * BK2 * 2, 0, 0);
             }
         }
     };
@@ -662,6 +675,8 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                     cur_ld = a.src[1].ld;
                     cur_c = a.src[1].c;
                     cur_nt = a.src[1].ntaps;
+                    srd_a_hi = make_srd(cur_hi);
+                    srd_a_lo = make_srd(cur_lo ? cur_lo : cur_hi);
                 }
             }
             if (s < a.nsrc) locate();
@@ -896,6 +911,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
     }
 
     wd_epilogue_lds<BM, BN, TN, 256 * KS>(a, acc, smem, m0, n0, wm, wn, WCOLS, kh, KS, tid, sidx);
+#endif
 }
 
 // ======================================================================================================
@@ -908,6 +924,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
 // layout is tied to 128-row panels) stay with the v2 kernel.
 template <int NPASS>
 __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, BN = 160, BK = 32;
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int A_PL = BM * 64, B_PL = BN * 64;
@@ -959,16 +976,20 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
     }
     __syncthreads();
 
-    long b_off[B_INS];
-    bool b_ok[B_INS];
+    // buffer_load ... lds addressing as in wd_gemm2_kernel: resources in SGPRs, 32-bit per-lane byte offsets, the stage's position
+    // in the scalar offset, offsets beyond num_records (padding / out-of-range rows) read as zeros
+    constexpr uint32_t WD_OOB = 0x80000000u;
+    auto make_srd = [](const wd_bf16* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<wd_bf16*>(p), 0, 0x7FFFFFF0, 0x00020000);
+    };
+    uint32_t b_voff[B_INS];
 #pragma unroll
     for (int i = 0; i < B_INS; ++i) {
         const int piece = wave + 4 * i;
         const int n = n0 + piece * 16 + lrow;
-        b_ok[i] = (piece < B_PIECES) && (n < a.n);
-        b_off[i] = (long)n * a.ktot + sw;
+        b_voff[i] = ((piece < B_PIECES) && (n < a.n)) ? (uint32_t)(((long)n * a.ktot + sw) * 2) : WD_OOB;
     }
-    const wd_bf16* zline = reinterpret_cast<const wd_bf16*>(wd_zero_line) + lpos * 8;
+    const __amdgpu_buffer_rsrc_t srd_w_hi = make_srd(a.w_hi), srd_w_lo = make_srd(a.w_lo ? a.w_lo : a.w_hi);
 
     const int nk_all = a.ktot / BK;
     const int k_begin = (int)((long)nk_all * sidx / a.ksplit), k_end = (int)((long)nk_all * (sidx + 1) / a.ksplit);
@@ -991,7 +1012,8 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
             cur_nt = a.src[1].ntaps;
         }
     }
-    long a_off[A_INS];
+    __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(cur_hi), srd_a_lo = make_srd(cur_lo ? cur_lo : cur_hi);
+    uint32_t a_voff[A_INS];
     auto locate = [&]() {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
@@ -999,34 +1021,30 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
             int r;
             if (s == 0) r = s_tab[tap * BM + row];
             else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
-            a_off[i] = r >= 0 ? (long)r * cur_ld + sw : -1;
+            a_voff[i] = r >= 0 ? (uint32_t)r * (uint32_t)(cur_ld * 2) + (uint32_t)(sw * 2) : WD_OOB;
         }
     };
     locate();
-    auto issue_a = [&](int i, char* sbase) {
-        const int piece = wave + 4 * i;
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-            const wd_bf16* src = a_off[i] >= 0 ? (p ? cur_lo : cur_hi) + a_off[i] + kc * BK : zline;
-            __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16, 0, 0);
-        }
-    };
-    auto issue_b = [&](int i, int kit, char* sbase) {
-        const int piece = wave + 4 * i;
-        if (piece < B_PIECES) {
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                const wd_bf16* src = b_ok[i] ? (p ? a.w_lo : a.w_hi) + b_off[i] + (long)kit * BK : zline;
-                __builtin_amdgcn_global_load_lds((wd_gbl_ptr)src, (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16, 0,
-                                                 0);
-            }
-        }
-    };
     auto issue = [&](int kit, char* sbase) {
 #pragma unroll
-        for (int i = 0; i < A_INS; ++i) issue_a(i, sbase);
+        for (int i = 0; i < A_INS; ++i) {
+            const int piece = wave + 4 * i;
 #pragma unroll
-        for (int i = 0; i < B_INS; ++i) issue_b(i, kit, sbase);
+            for (int p = 0; p < NPL; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? srd_a_lo : srd_a_hi, (wd_lds_ptr)(sbase + p * A_PL + piece * 1024), 16,
+                                                         a_voff[i], kc * BK * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INS; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < B_PIECES) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? srd_w_lo : srd_w_hi,
+                                                             (wd_lds_ptr)(sbase + NPL * A_PL + p * B_PL + piece * 1024), 16, b_voff[i],
+                                                             kit * BK * 2, 0, 0);
+            }
+        }
     };
     auto advance = [&]() {
         ++kc;
@@ -1042,6 +1060,8 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
                     cur_ld = a.src[1].ld;
                     cur_c = a.src[1].c;
                     cur_nt = a.src[1].ntaps;
+                    srd_a_hi = make_srd(cur_hi);
+                    srd_a_lo = make_srd(cur_lo ? cur_lo : cur_hi);
                 }
             }
             if (s < a.nsrc) locate();
@@ -1118,6 +1138,7 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
         wd_epilogue_tail<64, BN, 256>(a, ep, m0 + half * 64, n0, tid, sidx);
         __syncthreads();
     }
+#endif
 }
 
 // ======================================================================================================
@@ -1943,6 +1964,15 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         k += (long)q.ntaps * q.c;
     }
     if (k != a.ktot) return WD_EINVAL;
+    {   // the main kernel addresses every operand plane with 31-bit byte offsets (buffer_load ... lds)
+        const long lim = 0x7FFFFFF0L;
+        if ((long)a.n * a.ktot * 2 >= lim) return WD_EINVAL;
+        for (int s = 0; s < a.nsrc; ++s) {
+            const wd_src& q = a.src[s];
+            const long rows = q.gather ? (long)((a.m + a.hw_out - 1) / a.hw_out) * q.hw_src : (long)a.m;
+            if (rows * q.ld * 2 >= lim) return WD_EINVAL;
+        }
+    }
     if (a.act == WD_ACT_GEGLU && (a.n % 64 || a.tile == 0)) return WD_EINVAL;  // the tile fixes the x|gate packing
     if (a.rowvec && a.rowvec_ld <= 0) return WD_EINVAL;
     if (a.resid && a.resid_ld <= 0) return WD_EINVAL;
