@@ -1,3 +1,4 @@
+"""Micro-benchmark of wd_gn_conv3x3_few (GroupNorm + SiLU + 3x3 convolution to 4 channels + NCHW) at the headline shape."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from worddiffusion_amd import _native as N
