@@ -1582,8 +1582,47 @@ int launch_reduce(const wd_gemm_args& a, hipStream_t st) {
 // the combine pass is pure streaming: narrow column tiles so that it fills the chip (whole statistics groups per tile
 // when the GroupNorm sums are fused in).  The statistics layout is indexed by chunks of BM rows when a sample has more
 // rows than that, so the 64-row tile is only used where it leaves that layout unchanged (samples of <= 64 rows).
+// The combine for plain fp32 outputs (no statistics, row vector, activation or planes - every weight-gradient GEMM of the
+// training step): a pure stream, one float4 of the output per thread, the slabs summed in ascending order; bias and the
+// residual (gradient accumulation) are the only epilogue terms.  Half the time of the tile-shaped combine above.
+__global__ void __launch_bounds__(256) wd_gemm_reduce_flat_kernel(const wd_gemm_args a) {
+    const long total = (long)a.m * a.n, n4 = a.n >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.m * n4) return;
+    const long m = i / n4;
+    const int n = (int)(i - m * n4) * 4;
+    const float* p = a.ws + m * a.n + n;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+        const float4 q = *reinterpret_cast<const float4*>(p + (long)sp * total);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if (a.bias) {
+        const float4 q = *reinterpret_cast<const float4*>(a.bias + n);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if (a.resid) {
+        const float4 q = *reinterpret_cast<const float4*>(a.resid + m * a.resid_ld + n);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(a.out_f32 + m * a.out_ld + n) = v;
+}
+
+static bool reduce_flat_ok(const wd_gemm_args& a) {
+    return !a.stat_part && !a.rowvec && !a.resid_rows && a.act == WD_ACT_NONE && !a.out_hi && a.out_f32 && (a.n & 3) == 0 &&
+           (a.out_ld & 3) == 0 && (!a.resid || (a.resid_ld & 3) == 0) &&
+           ((reinterpret_cast<uintptr_t>(a.out_f32) | reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.resid) |
+             reinterpret_cast<uintptr_t>(a.ws)) & 15) == 0;
+}
+
 template <int BM, int BN>
 int launch_reduce_any(const wd_gemm_args& a, hipStream_t st) {
+    if (reduce_flat_ok(a)) {
+        WdLaunchScope scope(WD_CLS_GEMM_REDUCE, st);
+        const long items = (long)a.m * (a.n >> 2);
+        hipLaunchKernelGGL(wd_gemm_reduce_flat_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a);
+        return wd_check_launch();
+    }
     const int cpg = a.stat_part ? a.stat_cpg : 1;
     const bool half_rows = BM == 128 && (!a.stat_part || (a.hw_out <= 64 && 64 % a.hw_out == 0));
     if (40 % cpg == 0) return half_rows ? launch_reduce<64, 40>(a, st) : launch_reduce<128, 40>(a, st);
