@@ -29,6 +29,47 @@ __device__ __forceinline__ int geglu_perm(int n, int N, int g) {
     return (m / g) * 2 * g + half * g + (m % g);
 }
 
+template <int T>
+__device__ __forceinline__ void repack_full_tile(const PackRef& e, float* s, const int n0, const int c0, const int tid) {
+    constexpr int ROW = PT * T + 1;
+    const int C = e.C, N = e.N;
+    // load: for each output channel the (c, t) block of PT * T floats is contiguous in the OIHW source
+    for (int idx = tid; idx < PT * PT * T; idx += 256) {
+        const int nl = idx / (PT * T), rem = idx - nl * (PT * T);
+        const int n = n0 + nl;
+        s[nl * ROW + rem] = n < N ? e.src0[((int64_t)n * C + c0) * T + rem] : 0.f;
+    }
+    __syncthreads();
+    uint32_t* dh = reinterpret_cast<uint32_t*>(e.dst_hi);
+    uint32_t* dl = reinterpret_cast<uint32_t*>(e.dst_lo);
+    const int pr = tid & 15, r0 = tid >> 4;  // pr: element pair inside the 32-wide run, r0: one of 16 run lanes
+    if (e.mode == 0) {
+        // dst[perm(n)][t * C + c]: c fastest -> runs of 32 channels per (n, t)
+        for (int r = r0; r < PT * T; r += 16) {
+            const int nl = r / T, t = r - nl * T;
+            const int n = n0 + nl;
+            if (n >= N) continue;
+            uint32_t h0, l0, h1, l1;
+            wd_split1(s[nl * ROW + (2 * pr) * T + t], h0, l0);
+            wd_split1(s[nl * ROW + (2 * pr + 1) * T + t], h1, l1);
+            const int64_t o = ((int64_t)geglu_perm(n, N, e.g) * e.ld + (int64_t)t * C + c0 + 2 * pr) >> 1;
+            dh[o] = h0 | (h1 << 16);
+            if (dl) dl[o] = l0 | (l1 << 16);
+        }
+    } else {
+        // dst[c][t * npad + n]: n fastest -> runs of 32 output channels per (c, t); columns n >= N are written as zeros
+        for (int r = r0; r < PT * T; r += 16) {
+            const int cl = r / T, t = r - cl * T;
+            uint32_t h0, l0, h1, l1;
+            wd_split1(s[(2 * pr) * ROW + cl * T + t], h0, l0);
+            wd_split1(s[(2 * pr + 1) * ROW + cl * T + t], h1, l1);
+            const int64_t o = ((int64_t)(c0 + cl) * e.ld + (int64_t)t * e.npad + n0 + 2 * pr) >> 1;
+            dh[o] = h0 | (h1 << 16);
+            if (dl) dl[o] = l0 | (l1 << 16);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) repack_multi_kernel(const PackRef* __restrict__ tab, int nentries) {
     __shared__ float s[PT * (PT * 9 + 1)];
     int lo = 0, hi = nentries - 1;
@@ -55,6 +96,14 @@ __global__ void __launch_bounds__(256) repack_multi_kernel(const PackRef* __rest
     const int n0 = (int)(lc / e.ntile_c) * PT, c0 = (int)(lc % e.ntile_c) * PT;
     const int nc = min(PT, C - c0);           // valid input channels in this tile
     const int row = PT * T + 1;
+    if (nc == PT && (T == 9 || T == 1) && (e.mode == 0 || e.npad - n0 >= PT) && (C & 1) == 0 && (e.ld & 1) == 0 &&
+        (e.npad & 1) == 0 && ((reinterpret_cast<uintptr_t>(e.dst_hi) | reinterpret_cast<uintptr_t>(e.dst_lo)) & 3) == 0) {
+        // full tile: every index below is a shift / a division by a compile-time constant (the generic path spends ~100
+        // instructions per element on run-time div / mod), and the planes are written two elements (4 bytes) at a time
+        if (T == 9) repack_full_tile<9>(e, s, n0, c0, tid);
+        else repack_full_tile<1>(e, s, n0, c0, tid);
+        return;
+    }
     // load: for each output channel the (c, t) block is contiguous in the OIHW source
     for (int idx = tid; idx < PT * nc * T; idx += 256) {
         const int nl = idx / (nc * T), rem = idx - nl * (nc * T);
