@@ -35,9 +35,12 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * 64 + ((ch
 constexpr int WD_STAT_SCRATCH = 40 * 1024;  // LDS behind the epilogue image for the per-thread column sums
 constexpr int WD_STAT_MAXNS = 2;          // samples per 128-row panel the fused statistics support (hw_out >= 64)
 
-template <int BM, int BN, int NT>
+// WS: the tile's values are not in the LDS image but still spread over the split-K slabs of a.ws - the combine pass sums them
+// here, row by row in the thread's own (row lane, column quad) pattern, instead of staging the sums through LDS first (the
+// statistics scratch behind the image position is used as usual).  Vector path only; the caller checks.
+template <int BM, int BN, int NT, bool WS = false>
 __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, float* ep, const int m0, const int n0,
-                                                       const int tid) {
+                                                       const int tid, const int nslab = 1) {
     constexpr int LDE = BN + 4;  // row pitch in floats (16-byte aligned rows, bank-shifted)
     const bool geglu = a.act == WD_ACT_GEGLU;
     const int ocols = geglu ? BN / 2 : BN;  // output columns of this tile
@@ -98,7 +101,18 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
             for (int row = rl; row < BM; row += nrl) {
                 const int m = m0 + row;
                 if (m >= a.m) break;
-                float4 v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+                float4 v;
+                if constexpr (WS) {
+                    const float* p = a.ws + (long)m * a.n + n0 + c;
+                    const long total = (long)a.m * a.n;
+                    v = *reinterpret_cast<const float4*>(p);
+                    for (int sp = 1; sp < nslab; ++sp) {
+                        const float4 q = *reinterpret_cast<const float4*>(p + (long)sp * total);
+                        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                    }
+                } else {
+                    v = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+                }
                 if (geglu) {  // columns [0, BN/2) of the tile are x, [BN/2, BN) their gates (weights packed that way)
                     const float4 g = *reinterpret_cast<const float4*>(ep + row * LDE + c + BN / 2);
                     v.x = (v.x + bx.x) * wd_gelu_erf(g.x + bg.x);
@@ -1513,6 +1527,22 @@ __global__ void __launch_bounds__(256) wd_gemm_reduce_kernel(const wd_gemm_args 
     const int tid = threadIdx.x;
     const long total = (long)a.m * a.n;
     const bool v4 = (a.n & 3) == 0;
+    {
+        // the epilogue's vector path can sum the slabs itself (no LDS image, one barrier less, the slab / residual / row-vector
+        // loads of a row in flight together); same conditions as its own `vec` test plus aligned slabs
+        const bool direct = v4 && (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) == 0) &&
+                            (((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) |
+                               reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.out_f32) |
+                               reinterpret_cast<uintptr_t>(a.ws)) & 15) == 0) &&
+                            (((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) == 0) &&
+                            n0 + BN <= a.n;
+        if (direct) {
+            wd_gemm_args b = a;
+            b.ksplit = 1;
+            wd_epilogue_from_image<BM, BN, 256, true>(b, ep, m0, n0, tid, a.ksplit);
+            return;
+        }
+    }
     if (v4) {
         // slab-major with all of the thread's elements in flight per slab: the pass is latency-bound otherwise (one
         // workgroup's worth of loads per CU).  Per element the slabs are still summed in ascending order.
