@@ -84,7 +84,8 @@ typedef struct wd_gemm_args {
     int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192
                            * w_layout 2: w = [n][ktot] as for 0, src[0] is a 3x3 / pad 1 / stride 1 convolution (9 taps, its usual
                            * gather table) over images of width slab_rows, src[1] (optional) an identity source: selects the
-                           * kernel that loads the A tile of a kernel row once for its three taps */
+                           * kernel that loads the A tile of a kernel row once for its three taps when WDIFF_CONV3=1; in every case
+                           * it lets the kernel compute the source rows of a panel instead of reading the gather table */
     int32_t ksplit;       /* 1: off.  >1: the K range is cut into ksplit slices run by separate workgroups (fills the chip
                            * when m*n is small); partial sums go to ws and are combined in fixed order.  0: automatic
                            * (splits only when ws is given and the tile grid would leave most CUs idle) */

@@ -532,12 +532,19 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
         const int nt0 = a.src[0].ntaps;
         const int32_t* g0 = a.src[0].gather;
         const int hw_src0 = a.src[0].hw_src;
+        const int Wimg = a.slab_rows;  // > 0: 3x3 / pad 1 / stride 1 over images Wimg wide (wd_gemm() checked): arithmetic table
         for (int idx = tid; idx < nt0 * BM; idx += 256 * KS) {
             const int t = idx / BM, row = idx - t * BM;
             const int m = m0 + row;
             int v = -1;
             if (m < a.m) {
-                if (g0) {
+                if (g0 && Wimg > 0) {
+                    const int b = m / a.hw_out, p = m - b * a.hw_out;
+                    const int y = p / Wimg, x = p - y * Wimg;
+                    const int ky = t / 3, dy = ky - 1, dx = t - ky * 3 - 1;
+                    const int sy = y + dy, sx = x + dx;
+                    if (sy >= 0 && sy * Wimg < a.hw_out && sx >= 0 && sx < Wimg) v = b * hw_src0 + sy * Wimg + sx;
+                } else if (g0) {
                     const int b = m / a.hw_out, p = m - b * a.hw_out;
                     const int g = g0[t * a.hw_out + p];
                     if (g >= 0) v = b * hw_src0 + g;
@@ -2113,11 +2120,18 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         // row-shared taps (wd_conv3_kernel): 3x3 / pad 1 / stride 1 over images of width slab_rows, optional identity source.
         // The operand layout is the ordinary one, so this is a hint: shapes the kernel does not cover take the generic path.
         const wd_src& q0 = a.src[0];
-        conv3 = q0.ntaps == 9 && q0.gather && q0.c % 64 == 0 && a.slab_rows > 0 && q0.hw_src == a.hw_out &&
-                a.hw_out % a.slab_rows == 0 && a.act != WD_ACT_GEGLU && (a.tile == 0 || a.tile == 128160) &&
+        static const bool conv3_env = getenv("WDIFF_CONV3") ? atoi(getenv("WDIFF_CONV3")) != 0 : false;
+        const bool same3 = q0.ntaps == 9 && q0.gather && a.slab_rows > 0 && q0.hw_src == a.hw_out && a.hw_out % a.slab_rows == 0;
+        conv3 = conv3_env && same3 && q0.c % 64 == 0 && a.act != WD_ACT_GEGLU && (a.tile == 0 || a.tile == 128160) &&
                 (a.nsrc == 1 || (!a.src[1].gather && a.src[1].ntaps == 1 && a.src[1].c % 64 == 0));
         if (conv3) a.tile = 128160;
         a.w_layout = 0;
+        // generic kernel: slab_rows > 0 now means "src[0] is a 3x3 / pad 1 / stride 1 window over images slab_rows wide" - the
+        // source-row table of a panel is then computed, not looked up (saves the dependent global loads of the prologue)
+        static const bool arith_env = getenv("WDIFF_GEMM_ARITH_TAB") ? atoi(getenv("WDIFF_GEMM_ARITH_TAB")) != 0 : true;
+        if (!same3 || !arith_env) a.slab_rows = 0;
+    } else if (a.w_layout == 0) {
+        a.slab_rows = 0;
     } else if (a.w_layout != 0) {
         return WD_EINVAL;
     }

@@ -519,7 +519,8 @@ class UNetEngine:
         else:
             a.w_hi = wp[0].data_ptr() + 2 * w_row_off * ktot
             a.w_lo = wp[1].data_ptr() + 2 * w_row_off * ktot
-            same_w = getattr(srcs[0], "_same_w", 0) if self.use_conv3 else 0
+            same_w = getattr(srcs[0], "_same_w", 0)  # (a hint: lets the kernel compute the source-row table; WDIFF_CONV3=1 also
+            #                                           selects the row-shared-taps kernel for it)
             if (same_w and srcs[0].ntaps == 9 and srcs[0].c % 64 == 0 and act == N.ACT_NONE and tile == 0 and
                     (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather and srcs[1].c % 64 == 0))):
                 a.w_layout, a.slab_rows = 2, same_w  # 3x3 same-convolution: the taps of a kernel row share their A tile
