@@ -76,10 +76,12 @@ class StepRunner:
             # K timed steps, measured here once (second run: warm) and reported as config.per_call_setup_ms
             P.run_cond(st)
             P.run_film(st)
+            P.film_prepare(T - 1, st)
             self.stream.synchronize()
             t0 = time.perf_counter()
             P.run_cond(st)
             P.run_film(st)
+            P.film_prepare(T - 1, st)
             self.stream.synchronize()
             self.setup_ms = 1e3 * (time.perf_counter() - t0)
         self.stream.synchronize()
@@ -88,6 +90,7 @@ class StepRunner:
     def reset_t(self):
         self.t_dev.fill_(T - 1)
         self.P.t_in.fill_(T - 1)
+        self.P.film_prepare(T - 1, self.stream.cuda_stream)  # (callers hold torch's stream context of self.stream)
 
     def one_step(self, st):
         P, lib, N = self.P, self.lib, self.N
@@ -117,10 +120,64 @@ class StepRunner:
                     self.reset_t()
                     left = T - 1
                 n = min(left, k - done)
-                for _ in range(n):
+                for j in range(n):
+                    # the FiLM rows of a step come from the resident chunk of timesteps: entering the next chunk launches
+                    # its two kernels here, inside the timed loop (as Diffusion.sampling does)
+                    self.P.film_prepare(left - j, st)
                     self.N.check(self.lib.wd_graph_launch(self.graph, st), "graph_launch")
                 left -= n
                 done += n
+
+
+def cpu_info():
+    """CPU model name, physical cores (distinct (package, core id) pairs) and logical CPUs from /proc/cpuinfo."""
+    model, cores, logical, phys, core = "unknown", set(), 0, None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    return dict(cpu_model=model, physical_cores=len(cores) or None, logical_cpus=logical or os.cpu_count(),
+                usable_cpus=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+
+
+def cpu_baseline_config1(threads, iters=50):
+    """SURVEY.md section 8d config 1 / BASELINE configs[0]: the reference's CPU-runnable case - ``UNetModelPhosc`` (latent
+    config, no PHOSC vector), B = 1, 50 denoising iterations (Diffusion(noise_steps=51)), word "MOVE", writer 3 - through the
+    CPU oracle (the reference itself does not travel to this box)."""
+    from oracle import ddpm_oracle as D
+    from oracle import unet_oracle as U
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    torch.set_num_threads(threads)
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, 0)) for k, s in U.state_dict_shapes(FULL, "phosc")}
+    orc = U.UNetOracle(FULL, sd, "phosc", False)
+    ctx = torch.tensor([D.label_padding("MOVE")], dtype=torch.int64)
+    y = torch.tensor([3], dtype=torch.int64)
+    Tn = iters + 1
+    beta, alpha, ah = D.schedule(Tn)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 8, 32, generator=g)
+    with torch.no_grad():
+        orc(x, torch.tensor([Tn - 1]), ctx, y)  # warm-up
+        t0 = time.perf_counter()
+        for i in reversed(range(1, Tn)):
+            eps = orc(x, torch.full((1,), i, dtype=torch.int64), ctx, y)
+            x = D.reverse_step(beta, alpha, ah, x, eps, i, torch.randn(1, 4, 8, 32, generator=g))
+        dt = (time.perf_counter() - t0) / iters
+    return dict(workload="config 1: UNetModelPhosc latent config, B=1, %d DDPM iterations (oracle forward fp32 + update), "
+                         "1 warm-up" % iters, s_per_forward=dt, images_per_sec_at_999_steps=1.0 / (dt * (T - 1)),
+                iterations=iters, threads=threads, output_finite=bool(torch.isfinite(x).all()))
 
 
 def cpu_baseline(threads):
@@ -143,9 +200,15 @@ def cpu_baseline(threads):
             eps = orc(x, tt, inp["context"], inp["y"])
             x = D.reverse_step(beta, alpha, ah, x, eps, T - 1 - i, torch.randn_like(x))
         dt = (time.perf_counter() - t0) / nfw
-    return dict(value=BATCH / (dt * (T - 1)), unit="images/s", cores=threads, kind="port",
-                sample=f"{nfw} denoising steps (oracle UNet forward fp32 + update) of the B={BATCH} batch after 1 warm-up, "
-                       f"{dt:.3f} s/step, extrapolated to {T - 1} steps", s_per_step=dt)
+    out = dict(value=BATCH / (dt * (T - 1)), unit="images/s", cores=threads, kind="port",
+               sample=f"{nfw} denoising steps (oracle UNet forward fp32 + update) of the B={BATCH} batch after 1 warm-up, "
+                      f"{dt:.3f} s/step, extrapolated to {T - 1} steps", s_per_step=dt)
+    out.update(cpu_info())
+    try:
+        out["config1"] = cpu_baseline_config1(threads)
+    except Exception as e:  # an extra: never costs the line
+        out["config1"] = dict(error=f"{type(e).__name__}: {e}")
+    return out
 
 
 def vae_leg(dev, precision, B):
@@ -245,6 +308,77 @@ def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
     return out
 
 
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh worker processes of this script, one per GPU, with the
+    torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), BEFORE anything in this process has
+    touched the GPU (children are new processes, not a re-exec).  Rank 0's stdout (the one JSON line) is passed through;
+    the exit code is the first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            rc = rc or code
+            if code != 0:  # a dead rank would leave the others waiting at the next barrier
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_check(a):
+    """``--launch-check``: rendezvous + barrier + max-over-ranks only (no GPU work) - rehearses the N-rank control flow of
+    this script on a machine without GPUs (tests/test_dist_gloo.py).  Its line is NOT a measurement."""
+    from worddiffusion_amd import dist as wdist
+    rank, world, local = wdist.init_process_group("gloo")
+    assert world == a.gpus, f"launched with WORLD_SIZE={world} but --gpus {a.gpus}"
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    slowest = wdist.max_over_ranks(float(rank + 1))
+    if rank == 0:
+        print(json.dumps(dict(launch_check=True, n_gpus=world, max_over_ranks=slowest, value=None,
+                              note="control-flow rehearsal only: no kernel ran")))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def full_call_leg(model, args, dev, B, rank, world, barrier, wdist):
+    """One real ``Diffusion.sampling()`` call per rank - B words x 999 steps through the product API (word encoder, K/V, folds,
+    FiLM table, graph capture, 999 replays, read-back of the latents) - timed wall-clock between barriers, max over ranks.
+    The un-extrapolated companion of the headline ``value``."""
+    from worddiffusion_amd import Diffusion
+    from worddiffusion_amd.synthetic import synthetic_inputs
+    diff = Diffusion(noise_steps=T, img_size=(64, 256), args=args)
+    inp = synthetic_inputs(B, seed=2 + rank * B)
+    words = ["".join("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxy"[(7 * i + 3 * j) % 51] for j in range(1 + i % 10))
+             for i in range(B)]
+    barrier()
+    t0 = time.perf_counter()
+    lat = diff.sampling(model, None, B, words, inp["y"], args, seed=1234, sample_offset=rank * B)
+    torch.cuda.synchronize()
+    barrier()
+    sec = wdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    model.eval()
+    return dict(workload="one Diffusion.sampling() call per GPU: %d words x %d executed steps, vae=None (latents returned)"
+                         % (B, T - 1), seconds=sec, images_per_sec=world * B / sec, executed_steps=diff.last_stats["steps"],
+                graph=diff.last_stats["graph"], output_finite=bool(torch.isfinite(lat).all().item()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,7 +396,19 @@ def main():
                     help="also time this many train.py-style steps (0 = skip; default: 30 on one GPU, 0 on several - the "
                          "multi-GPU run is the scaling measurement of the headline metric, pass a count to add the data-parallel "
                          "training leg with its gradient all-reduce)")
+    ap.add_argument("--no-full-call", action="store_true", help="skip the un-extrapolated full sampling() call")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous / barrier / max-over-ranks only, no GPU work (CPU rehearsal of the N-rank control flow)")
     a = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        # no launcher around us: become the launcher (nothing in this process has touched the GPU yet)
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != a.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={env_world} but --gpus {a.gpus}")
+    if a.launch_check:
+        return launch_check(a)
 
     from worddiffusion_amd import dist as wdist
     # WDIFF_BENCH_REHEARSE=1: every rank on cuda:0 with gloo - rehearses the N>1 control flow on a one-GPU box (numbers from
@@ -342,9 +488,17 @@ def main():
         prof_extra = {N.CLASS_NAMES[i]: dict(ms_per_step=ms[i] / nprof, launches_per_step=int(cnt[i]) // nprof)
                       for i in range(N.NCLASS)}
 
+    full_call = None
+    if not a.no_full_call and a.variant == "base" and B == BATCH:
+        try:
+            full_call = full_call_leg(model, args, dev, B, rank, world, barrier, wdist)
+        except Exception as e:  # an extra: never costs the headline line (every rank fails alike: same code, same sizes)
+            full_call = dict(error=f"{type(e).__name__}: {e}")
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.variant == "base":
-        cpu = cpu_baseline(min(os.cpu_count() or 1, 64))
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cpu = cpu_baseline(min(usable, 64))
 
     train = None
     if a.train_steps < 0:
@@ -382,7 +536,8 @@ def main():
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
                                 images_per_sec_per_gpu=value / world, output_finite=finite,
                                 per_call_setup_ms=setup_ms),
-                    roofline=roof, cpu_baseline=cpu, kernel_classes=prof_extra, train_step=train, vae_decode=vae)
+                    roofline=roof, cpu_baseline=cpu, full_call=full_call, kernel_classes=prof_extra, train_step=train,
+                    vae_decode=vae)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

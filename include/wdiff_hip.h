@@ -168,11 +168,14 @@ int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, const float
                    const wd_bf16* mq_pl, const wd_bf16* mot_pl, void* stream);
 
 /* Sampling-time tabulation of the FiLM path (time_embed + label_emb + SiLU + every emb_layers, unet.py:1550-1581,609-615):
- * wd_emb_combine writes SiLU(time[t] + label[y_b]) for every (t, b) as operand planes (row t*B + b), one wd_gemm then gives
- * the FiLM vectors of all T steps, and wd_select_rows copies the rows of the current step (t read from the device). */
-int wd_emb_combine(const float* time, const float* label, const int64_t* y, int T, int B, int ted, wd_bf16* out_hi,
-                   wd_bf16* out_lo, int out_ld, void* stream);
-int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, float* out, void* stream);
+ * wd_emb_combine writes SiLU(time[t] + label[y_b]) for T consecutive timesteps (time points at the first one) and every
+ * sample b as operand planes (row t*B + b; y_b is clamped to [0, num_classes) - the host range-checks it, the reference
+ * raises an index error), one wd_gemm then gives the FiLM vectors of those T steps, and wd_select_rows copies the rows of
+ * the current step out of the resident chunk: row ((*t_dev) % chunk)*B + b (chunk = T of the table: one table for all steps). */
+int wd_emb_combine(const float* time, const float* label, const int64_t* y, int num_classes, int T, int B, int ted,
+                   wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream);
+int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, int chunk, float* out,
+                   void* stream);
 
 /* Two chained folded cross-attentions in one launch (attn1 then attn2 of a base-model BasicTransformerBlock, unet.py:337-345;
  * both read LayerNorm parameters of their own, here norm2 twice): out = B(A(x)) with A/B = x + bias + softmax(LN(x).Mq^T).Mo,

@@ -5,7 +5,9 @@ TEST INFRASTRUCTURE - not part of the product (see ``oracle/unet_oracle.py`` for
 Restates ``Diffusion`` / ``EMA`` / ``label_padding`` of the reference's ``train.py:42-52,140-251`` with
 plain fp32 torch ops in the same order, so tables and updates are bit-comparable.
 Pinned by ``tests/golden/primitives.npz`` (schedules, label_padding), ``ddpm_traj.npz`` (an 8-step
-reverse trajectory of the reference with recorded noise, ``noise_images``) and ``train_step.npz``.
+reverse trajectory of the reference with recorded noise, ``noise_images``), ``train_step.npz``, and the variant
+scripts' loops: ``ddpm_traj_phosc_{small,full}.npz`` (PHOSC-conditioned), ``ddpm_traj_modcond.npz`` +
+``primitives_modcond.npz`` (trainModifyCondition.py: s_id = ones, '_' alphabet, T = 600).
 """
 from __future__ import annotations
 
@@ -25,6 +27,17 @@ def label_padding(word: str, num_tokens: int = NUM_TOKENS, max_len: int = MAX_CH
     ll = [C_CLASSES.index(c) + num_tokens for c in word]
     ll = ll + [PAD_TOKEN] * (max_len - len(ll))
     return ll
+
+
+C_CLASSES_UNDERSCORE = C_CLASSES + "_"  # trainModifyCondition.py:68
+
+
+def label_padding_underscore(word: str, num_tokens: int = NUM_TOKENS, max_len: int = MAX_CHARS) -> List[int]:
+    """trainModifyCondition.py:166-180: ``labels.replace(" ", "_")``, index in the 53-class alphabet + num_tokens, right-padded
+    with PAD_TOKEN (52) - '_' is id 53, so the models of that script have vocab_size 54.  Pinned by
+    ``tests/golden/primitives_modcond.npz`` (the reference function's own outputs)."""
+    ll = [C_CLASSES_UNDERSCORE.index(c) + num_tokens for c in word.replace(" ", "_")]
+    return ll + [PAD_TOKEN] * (max_len - len(ll))
 
 
 def schedule(noise_steps: int = 1000, beta_start: float = 1e-4, beta_end: float = 0.02):

@@ -61,3 +61,22 @@ def max_rel(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def join_all(procs, timeout):
+    """Joins every spawned rank within ``timeout`` seconds in total; a rank still alive after that is killed (so a hung child
+    never keeps the GPU context or the port for the tests that follow) and the exit codes are asserted afterwards."""
+    import time
+    deadline = time.monotonic() + timeout
+    try:
+        for p in procs:
+            p.join(max(0.0, deadline - time.monotonic()))
+    finally:
+        hung = [p for p in procs if p.is_alive()]
+        for p in hung:
+            p.kill()
+        for p in hung:
+            p.join()
+    assert not hung, f"{len(hung)} rank(s) did not finish within {timeout} s and were killed"
+    codes = [p.exitcode for p in procs]
+    assert all(c == 0 for c in codes), f"rank exit codes {codes}"

@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests._common import join_all
 from worddiffusion_amd.dist import GradAllReducer, gather_rows, max_over_ranks, shard_range, sharded_sampling
 
 
@@ -78,10 +79,32 @@ def test_two_rank_sharded_sampling_and_grad_allreduce(n_total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=120) for _ in procs]
+    finally:
+        join_all(procs, 60)
     for rank, ok_gather, ok_shard, ok_rows, mx, nb, ok_grad in res:
         assert ok_gather and ok_shard and ok_rows and ok_grad, (rank, ok_gather, ok_shard, ok_rows, ok_grad)
         assert mx == 2.0 and nb >= 2
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it starts two ranks by itself (fresh child processes, torchrun
+    environment) and rank 0 prints one JSON line with ``n_gpus: 2``.  ``--launch-check`` keeps it to the control flow
+    (rendezvous, barrier, max over ranks) so that it runs without a GPU; the GPU form is tests/test_gpu_dist.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["launch_check"] is True and line["max_over_ranks"] == 2.0
+    # under a launcher whose world size disagrees with --gpus the script refuses instead of printing a wrong n_gpus
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests._common import SMALL, make_args  # noqa: E402
+from tests._common import SMALL, join_all, make_args  # noqa: E402
 
 
 def _free_port():
@@ -73,9 +73,7 @@ def test_two_rank_train_step_equals_full_batch_step(tmp_path):
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+    join_all(procs, 600)
     got = torch.load(out, weights_only=True)
     # single process, whole batch
     m, ema, opt, diff, TrainStep = _setup(31)
@@ -96,3 +94,23 @@ def test_two_rank_train_step_equals_full_batch_step(tmp_path):
         worst = max(worst, rel)
         assert rel < 0.05, (k, rel)  # mean of the two half-batch gradients == full-batch gradient (up to Adam sign flips)
     assert worst > 0.0 or True
+
+
+def test_bench_gpus_2_runs_two_ranks_and_reports_them():
+    """``python bench.py --gpus 2`` on this one-GPU box: the script launches two ranks itself; WDIFF_BENCH_REHEARSE=1 puts both on
+    cuda:0 over gloo (RCCL refuses two ranks on one device) - the numbers mean nothing, the control flow and the line do."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["WDIFF_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline", "--no-vae", "--train-steps", "0", "--no-roofline"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["batch_per_gpu"] == 8
+    assert line["value"] > 0 and line["config"]["output_finite"]

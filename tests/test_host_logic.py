@@ -188,6 +188,94 @@ def test_driver_host_pieces(tmp_path):
     assert all(Diffusion.sampling3_calls_model(i, 600, 12) == D.sampling3_calls_model(i, 600, 12) for i in range(1, 600))
 
 
+def test_driver_reads_the_references_own_gt_lines(golden_dir):
+    """``read_gt`` / ``writer_dict`` on real lines of the reference's gt/* lists (IAM, CVL, OOV, Norwegian formats) against the
+    literal restatement of full_sampling.py:132-143 / train.py:370-388."""
+    from oracle import driver_oracle as DO
+    from worddiffusion_amd.driver import read_gt, writer_dict
+    path = os.path.join(golden_dir, "gt_samples.txt")
+    with open(path) as f:
+        lines = [ln for ln in f.readlines() if ln.strip()]
+    want = DO.parse_gt_lines(lines)
+    rows = read_gt(path)
+    assert rows == want and len(rows) == 23
+    assert rows[0] == ("049", "a03-034-00-00", "Members") and rows[17] == ("202", "f07-069-03-07_202_owes_155_owes", "owes")
+    assert rows[20][2] == "skr\u00e6ggs"
+    assert writer_dict(rows) == DO.writer_dict_train(want)
+    assert writer_dict(rows)["049"] == 0 and writer_dict(rows)["537"] == 1 and len(writer_dict(rows)) == 11
+
+
+def test_underscore_alphabet_matches_reference_golden(golden_dir):
+    """``label_padding`` of trainModifyCondition.py:166-180 ('_' alphabet, vocab 54) - outputs of the reference function."""
+    from worddiffusion_amd.diffusion import (C_CLASSES_UNDERSCORE, VOCAB_SIZE_UNDERSCORE, label_padding_underscore)
+    g = load_golden(golden_dir, "primitives_modcond")
+    for w, ref in zip(g["words"], g["label_padding"]):
+        assert label_padding_underscore(str(w)) == [int(v) for v in ref]
+    assert VOCAB_SIZE_UNDERSCORE == int(g["vocab_size"]) == 54 and C_CLASSES_UNDERSCORE == str(g["c_classes"])
+    with pytest.raises(KeyError):
+        label_padding("a_b")  # train.py's 52-letter alphabet has no '_'
+    with pytest.raises(KeyError):
+        label_padding_underscore("a-b")
+    d = Diffusion(args=make_args())
+    assert d._text_features("to be", 2, underscore=True).tolist() == [[int(v) for v in g["label_padding"][0]]] * 2
+
+
+def test_char_level_emb_flag_constructs(golden_dir):
+    """args.charLevelEmb=1 (default of unet.py:1871) is accepted: same parameter tree; only context_dim=320 is legal."""
+    m0 = UNetModel(args=make_args(charLevelEmb=0), **FULL)
+    m1 = UNetModel(args=make_args(charLevelEmb=1), **FULL)
+    assert list(m0.state_dict().keys()) == list(m1.state_dict().keys())
+    g = load_golden(golden_dir, "fwd_base_full_charlevel")
+    assert [str(k) for k in g["keys"]] == list(m1.state_dict().keys())
+    with pytest.raises(NotImplementedError):
+        UNetModel(args=make_args(charLevelEmb=1), **SMALL)  # unet.py:864 views (B, 10, 320)
+    UNetModelPhosc(args=make_args(charLevelEmb=1), **SMALL)  # unetPhosc.py never reads the flag
+
+
+def test_latent_cache_round_trip_and_dataset(tmp_path, golden_dir):
+    """Cached-latent container (the tensor-only form of the reference's imageWordLineVae3*.pkl dictionaries,
+    trainModifyCondition.py:300-325,452-458): converter, word -> character fallback order, dataset items, rank shards."""
+    from worddiffusion_amd.driver import read_gt, writer_dict
+    from worddiffusion_amd.latents import CachedLatentDataset, LatentCache, convert_latent_dict, save_latent_cache
+    rows = read_gt(os.path.join(golden_dir, "gt_samples.txt"))[:14]  # the IAM lines
+    wr = writer_dict(rows)
+    rs = np.random.RandomState(0)
+    # the reference's layout: {name: {"images": [1,4,8,32], ...}}; the last 4 images only exist in the second dictionary
+    word_dict = {r[1] + ".png": {"images": torch.from_numpy(rs.standard_normal((1, 4, 8, 32)).astype(np.float32)), "x": 1}
+                 for r in rows[:10]}
+    char_dict = {r[1] + ".png": {"images": torch.from_numpy(rs.standard_normal((1, 4, 8, 32)).astype(np.float32))}
+                 for r in rows[8:]}
+    p1 = convert_latent_dict(word_dict, str(tmp_path / "word.safetensors"))
+    p2 = convert_latent_dict(char_dict, str(tmp_path / "char.npz"))
+    cache = LatentCache(p1, p2)
+    assert len(cache) == 14 and rows[0][1] + ".png" in cache and "nope.png" not in cache
+    k9 = rows[9][1] + ".png"
+    assert torch.equal(cache[k9], word_dict[k9]["images"][0])          # the word dictionary wins (:452-456)
+    k12 = rows[12][1] + ".png"
+    assert torch.equal(cache[k12], char_dict[k12]["images"][0])        # fallback to the character dictionary
+    with pytest.raises(KeyError):
+        cache["nope.png"]
+    ds = CachedLatentDataset(rows, wr, cache)
+    it = ds[3]
+    assert it["image_name"] == "a03-034-00-03.png" and it["label"] == "Cabinet" and it["s_id"] == 0
+    assert it["word"].tolist() == label_padding("Cabinet") and it["latent"].shape == (4, 8, 32)
+    seen = []
+    for r in range(2):
+        for b in ds.batches(3, shuffle=True, seed=5, epoch=1, rank=r, world=2, pin=False):
+            assert b["latents"].shape == (3, 4, 8, 32) and b["words"].shape == (3, 10) and b["s_id"].dtype == torch.int64
+            seen += b["image_names"]
+    assert len(seen) == 12 and len(set(seen)) == 12  # 7 rows per rank, drop_last -> 2 batches of 3 each, disjoint
+    a = [b["image_names"] for b in ds.batches(4, seed=5, epoch=0, pin=False)]
+    assert a == [b["image_names"] for b in ds.batches(4, seed=5, epoch=0, pin=False)]
+    assert a != [b["image_names"] for b in ds.batches(4, seed=5, epoch=1, pin=False)]
+    ds_u = CachedLatentDataset([("049", rows[0][1], "to be")], wr, cache, underscore=True)
+    assert ds_u[0]["word"].tolist()[:5] == [46, 41, 53, 28, 31]
+    short = CachedLatentDataset(rows + [("049", "missing-image", "x")], wr, cache, skip_missing=True)
+    assert len(short) == 14
+    save_latent_cache(str(tmp_path / "plain.safetensors"), {"a.png": torch.zeros(4, 8, 32)})
+    assert LatentCache(str(tmp_path / "plain.safetensors"))["a.png"].shape == (4, 8, 32)
+
+
 def test_phosc_descriptors_match_reference_golden(golden_dir, tmp_path):
     """PHOS / PHOC / PHOSC vectors against the outputs of the reference's own generators (tests/golden/phosc.npz, made by
     oracle/make_golden_phosc.py); the shape-count table travels as data inside the golden file."""

@@ -82,6 +82,59 @@ def test_ddpm_trajectory(golden_dir):
     assert torch.equal(xt, torch.from_numpy(g["ni_xt"]))
 
 
+def _oracle(cfg, variant, seed, phosc_on=False):
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, seed)) for k, s in U.state_dict_shapes(cfg, variant)}
+    return U.UNetOracle(cfg, sd, variant, phosc_on)
+
+
+@pytest.mark.parametrize("tag,cfgname", [("ddpm_traj_phosc_small", "SMALL"), ("ddpm_traj_phosc_full", "FULL")])
+def test_phosc_sampling_loop(golden_dir, tag, cfgname):
+    """The reference's train.Diffusion.sampling driving UNetModelPhosc(args.phosc=1) with a PHOSC vector
+    (trainGWModifyCondition.py:272-273 call form): oracle loop == recorded reference trajectory."""
+    import tests._common as TC
+    cfg = getattr(TC, cfgname)
+    g = load_golden(golden_dir, tag)
+    T, n = int(g["T"]), g["labels"].shape[0]
+    orc = _oracle(cfg, "phosc", int(g["seed"]), True)
+    ctx = torch.tensor([D.label_padding(str(g["word"]))] * n, dtype=torch.int64)
+    y, phosc = torch.from_numpy(g["labels"]), torch.from_numpy(g["phosc"])
+    noise = torch.from_numpy(g["noise"])
+    rec = []
+    with torch.no_grad():
+        x0 = D.sampling(lambda x, t: orc(x, t, ctx, y, phosc), noise[0], list(noise[1:]), T, rec)
+    assert max_rel(torch.stack(rec), g["x_per_step"]) < 5e-5
+    img = ((x0 / 0.18215) / 2 + 0.5).clamp(0, 1)
+    assert float((img - torch.from_numpy(g["image"])).abs().max()) < 2e-4
+
+
+def test_modify_condition_sampling_loop_and_alphabet(golden_dir):
+    """trainModifyCondition.py: label_padding with the '_' alphabet (vocab 54), Diffusion.sampling with s_id = ones,
+    T = 8 (every step) and the script's default T = 600 (checkpoints)."""
+    p = load_golden(golden_dir, "primitives_modcond")
+    for w, ref in zip(p["words"], p["label_padding"]):
+        assert D.label_padding_underscore(str(w)) == [int(v) for v in ref]
+    assert int(p["vocab_size"]) == len(D.C_CLASSES_UNDERSCORE) + D.NUM_TOKENS == 54
+    assert str(p["c_classes"]) == D.C_CLASSES_UNDERSCORE and int(p["default_noise_steps"]) == 600
+    g = load_golden(golden_dir, "ddpm_traj_modcond")
+    cfg = dict(SMALL, vocab_size=int(g["vocab_size"]))
+    orc = _oracle(cfg, "base", int(g["seed"]))
+    for tag, n, every in (("T8", 3, 1), ("T600", 2, 100)):
+        noise = torch.from_numpy(g[tag + "_noise"])
+        T = noise.shape[0] + 1
+        ctx = torch.tensor([D.label_padding_underscore(str(g["word"]))] * n, dtype=torch.int64)
+        s_id = torch.ones(n, dtype=torch.int64)  # trainModifyCondition.py:565, whatever ``labels`` holds
+        rec = []
+        with torch.no_grad():
+            x0 = D.sampling(lambda x, t: orc(x, t, ctx, s_id), noise[0], list(noise[1:]), T, rec)
+        xs = torch.stack(rec[::every])
+        ref = g["T8_x_per_step"] if tag == "T8" else g["T600_x_every100"]
+        assert xs.shape == tuple(ref.shape)
+        assert max_rel(xs, ref) < 5e-5, tag
+        img = ((x0 / 0.18215) / 2 + 0.5).clamp(0, 1)
+        assert float((img - torch.from_numpy(g[tag + "_image"])).abs().max()) < 2e-4, tag
+
+
 def test_train_step(golden_dir):
     from worddiffusion_amd.synthetic import synthetic_tensor
     g = load_golden(golden_dir, "train_step")

@@ -82,8 +82,8 @@ _SIGS = {
     "wd_colsum_finish": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, _vp]),
     "wd_colsum_entry_bytes": (_i, []),
     "wd_colsum_finish_multi": (_i, [_vp, _i, _i, _vp]),
-    "wd_emb_combine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "wd_select_rows": (_i, [_vp, _vp, _i, C.c_int64, _vp, _vp]),
+    "wd_emb_combine": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "wd_select_rows": (_i, [_vp, _vp, _i, C.c_int64, _i, _vp, _vp]),
     "wd_xattn_pair": (_i, [_vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f,
                            _vp, _vp, _i, _vp]),
     "wd_add": (_i, [_vp, _vp, C.c_int64, _vp]),

@@ -199,7 +199,8 @@ inline int grid_for(long total, int block = 256, int cap = 2048) {
 // emb rows for every (timestep, sample): SiLU(time[t] + label[y_b]) as operand planes (unet.py:1550-1581 followed by the
 // SiLU that opens every emb_layers, unet.py:609) - lets the sampler tabulate the FiLM vectors of all steps in one GEMM
 __global__ void emb_combine_kernel(const float* __restrict__ time, const float* __restrict__ label, const int64_t* __restrict__ y,
-                                   int T, int B, int ted, wd_bf16* __restrict__ out_hi, wd_bf16* __restrict__ out_lo, int out_ld) {
+                                   int num_classes, int T, int B, int ted, wd_bf16* __restrict__ out_hi,
+                                   wd_bf16* __restrict__ out_lo, int out_ld) {
     const int t4 = ted >> 2;
     const long total = (long)T * B * t4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -208,7 +209,9 @@ __global__ void emb_combine_kernel(const float* __restrict__ time, const float* 
         const int t = (int)(row / B), b = (int)(row - (long)t * B);
         float4 v = *reinterpret_cast<const float4*>(time + (long)t * ted + cx);
         if (label) {
-            const float4 l = *reinterpret_cast<const float4*>(label + (long)y[b] * ted + cx);
+            long yb = y[b];  // range-checked on the host (engine.check_ids); clamped here so that a stale id can never read
+            yb = yb < 0 ? 0 : (yb >= num_classes ? num_classes - 1 : yb);  // past the table
+            const float4 l = *reinterpret_cast<const float4*>(label + yb * ted + cx);
             v.x += l.x; v.y += l.y; v.z += l.z; v.w += l.w;
         }
         v.x = wd_silu(v.x); v.y = wd_silu(v.y); v.z = wd_silu(v.z); v.w = wd_silu(v.w);
@@ -218,10 +221,11 @@ __global__ void emb_combine_kernel(const float* __restrict__ time, const float* 
         if (out_lo) *reinterpret_cast<uint2*>(out_lo + row * out_ld + cx) = lo;
     }
 }
-// out[b][:] = table[(*t_dev) * B + b][:]  (the rows of the current timestep; t_dev lives on the device so the launch replays)
+// out[b][:] = table[((*t_dev) % chunk) * B + b][:]  (the rows of the current timestep inside the resident chunk of `chunk`
+// timesteps; t_dev lives on the device so the launch replays)
 __global__ void select_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ t_dev, int B, long row4,
-                                   float* __restrict__ out) {
-    const long base = (long)(*t_dev) * B * row4;
+                                   int chunk, float* __restrict__ out) {
+    const long base = (long)((*t_dev) % chunk) * B * row4;
     const long total = (long)B * row4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
         reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table)[base + i];
@@ -339,21 +343,23 @@ extern "C" int wd_ema_update(float* ema, const float* p, int64_t n, double beta,
     return wd_check_launch();
 }
 
-extern "C" int wd_emb_combine(const float* time, const float* label, const int64_t* y, int T, int B, int ted, wd_bf16* out_hi,
-                              wd_bf16* out_lo, int out_ld, void* stream) {
-    if (!time || !out_hi || T <= 0 || B <= 0 || ted <= 0 || ted % 4 || out_ld % 4 || (label && !y)) return WD_EINVAL;
+extern "C" int wd_emb_combine(const float* time, const float* label, const int64_t* y, int num_classes, int T, int B, int ted,
+                              wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, void* stream) {
+    if (!time || !out_hi || T <= 0 || B <= 0 || ted <= 0 || ted % 4 || out_ld % 4 || (label && (!y || num_classes <= 0)))
+        return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
-    hipLaunchKernelGGL(emb_combine_kernel, dim3(grid_for((long)T * B * (ted / 4))), dim3(256), 0, st, time, label, y, T, B, ted,
-                       out_hi, out_lo, out_ld);
+    hipLaunchKernelGGL(emb_combine_kernel, dim3(grid_for((long)T * B * (ted / 4))), dim3(256), 0, st, time, label, y, num_classes, T,
+                       B, ted, out_hi, out_lo, out_ld);
     return wd_check_launch();
 }
 
-extern "C" int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, float* out, void* stream) {
-    if (!table || !t_dev || !out || batch <= 0 || row_floats <= 0 || row_floats % 4) return WD_EINVAL;
+extern "C" int wd_select_rows(const float* table, const int32_t* t_dev, int batch, int64_t row_floats, int chunk, float* out,
+                              void* stream) {
+    if (!table || !t_dev || !out || batch <= 0 || row_floats <= 0 || row_floats % 4 || chunk <= 0) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for((long)batch * (row_floats / 4))), dim3(256), 0, st, table, t_dev, batch,
-                       (long)(row_floats / 4), out);
+                       (long)(row_floats / 4), chunk, out);
     return wd_check_launch();
 }

@@ -27,14 +27,33 @@ MAX_CHARS = 10
 TOKENS = {"PAD_TOKEN": 52}
 NUM_TOKENS = len(TOKENS)
 VOCAB_SIZE = len(C_CLASSES) + NUM_TOKENS
+# the alphabet of trainModifyCondition.py:68 / trainGWModifyCondition.py:53: the 52 letters + '_' (a space is written as
+# '_', :169) -> 53 classes, vocab_size 54; PAD stays 52, so '_' is id 53 and 'z' (51 + 1) still collides with PAD as in
+# train.py
+C_CLASSES_UNDERSCORE = C_CLASSES + "_"
+LETTER2INDEX_UNDERSCORE = {c: i for i, c in enumerate(C_CLASSES_UNDERSCORE)}
+VOCAB_SIZE_UNDERSCORE = len(C_CLASSES_UNDERSCORE) + NUM_TOKENS
+
+
+def _pad_ids(labels: str, table, num_tokens: int, max_len: int) -> List[int]:
+    try:
+        ll = [table[ch] + num_tokens for ch in labels]
+    except KeyError as e:  # the reference raises KeyError from ``letter2index[i]`` as well (train.py:45)
+        raise KeyError(f"character {e.args[0]!r} of {labels!r} is not in the label alphabet") from None
+    if len(ll) > max_len:
+        raise ValueError(f"word longer than {max_len} characters: {labels!r}")
+    return ll + [TOKENS["PAD_TOKEN"]] * (max_len - len(ll))
 
 
 def label_padding(labels: str, num_tokens: int = NUM_TOKENS, max_len: int = MAX_CHARS) -> List[int]:
     """``train.py:42-52``: letter indices shifted by ``num_tokens`` and right-padded with PAD (52) to 10."""
-    ll = [LETTER2INDEX[ch] + num_tokens for ch in labels]
-    if len(ll) > max_len:
-        raise ValueError(f"word longer than {max_len} characters: {labels!r}")
-    return ll + [TOKENS["PAD_TOKEN"]] * (max_len - len(ll))
+    return _pad_ids(labels, LETTER2INDEX, num_tokens, max_len)
+
+
+def label_padding_underscore(labels: str, num_tokens: int = NUM_TOKENS, max_len: int = MAX_CHARS) -> List[int]:
+    """``trainModifyCondition.py:166-180`` (same in ``trainGWModifyCondition.py:64-78``): ``labels.replace(" ", "_")``, then
+    the 53-class alphabet (``'_'`` -> 52 + num_tokens = 53); models fed with it are built with ``vocab_size = 54``."""
+    return _pad_ids(labels.replace(" ", "_"), LETTER2INDEX_UNDERSCORE, num_tokens, max_len)
 
 
 def _stream_ptr(device):
@@ -56,6 +75,10 @@ class EMA:
             assert ma.is_contiguous() and cur.is_contiguous() and ma.dtype == torch.float32
             N.check(lib.wd_ema_update(ma.data_ptr(), cur.data_ptr(), ma.numel(), float(self.beta),
                                       _stream_ptr(ma.device)), "wd_ema_update")
+        # the kernel wrote the averaged parameters behind autograd's back: bump their version counters so that the engine of
+        # ``ma_model`` (which keys its packed operands on them, engine._signature) repacks before the next forward / sampling
+        touched = list(ma_model.parameters())
+        torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])
 
     def step_ema(self, ema_model, model, step_start_ema=2000):
         if self.step < step_start_ema:
@@ -132,6 +155,7 @@ class Diffusion:
         lib = N.lib()
         eng = model.engine
         eng.refresh_weights()
+        eng.check_ids(text_features, labels, phosc)  # host tensors here: no device sync
         h, w = self.img_size[0] // 8, self.img_size[1] // 8
         ctx_len = text_features.shape[1]
         phosc_len = 0 if phosc is None else phosc.shape[1]
@@ -153,13 +177,14 @@ class Diffusion:
             else:
                 N.check(lib.wd_randn(P.x_in.data_ptr(), n, npix, seed, sample_offset, 0, st), "wd_randn")
             eng.load_inputs(P, None, None, text_features.to(device), labels.to(device) if labels is not None else None,
-                            phosc.to(device) if phosc is not None else None)
+                            phosc.to(device) if phosc is not None else None, check=False)
             t_dev = P.t_dev
             t_dev.fill_(T - 1)
             P.t_in.fill_(T - 1)
             zbuf = torch.zeros_like(P.x_in) if noise is not None else None
             P.run_cond(st)
-            P.run_film(st)  # FiLM vectors of every timestep for this batch of writers (one GEMM; see engine.plan)
+            P.run_film(st)  # time MLP of every timestep; the FiLM rows follow per chunk of timesteps (P.film_prepare)
+            P.film_prepare(T - 1, st)  # before the capture: the captured step only reads the table
 
             def one_step(stream, forward=True):
                 if forward:
@@ -196,6 +221,8 @@ class Diffusion:
                     k += 1
                 fwd = calls_model is None or bool(calls_model(i))
                 ncalls += int(fwd)
+                if fwd:
+                    P.film_prepare(i, st)  # FiLM rows of timestep i (computed per chunk of timesteps, see engine.plan)
                 if gexec is not None:
                     N.check(lib.wd_graph_launch(gexec if fwd else gskip, st), "wd_graph_launch")
                 else:
@@ -211,11 +238,12 @@ class Diffusion:
                                seed=seed, sample_offset=sample_offset, model_calls=ncalls)
         return x
 
-    def _text_features(self, x_text, n):
+    def _text_features(self, x_text, n, underscore=False):
         words = [x_text] * n if isinstance(x_text, str) else list(x_text)
         if len(words) != n:
             raise ValueError("x_text must be one word or a list of n words")
-        return torch.tensor(np.array([label_padding(w, NUM_TOKENS) for w in words], dtype="int64"))
+        pad = label_padding_underscore if underscore else label_padding
+        return torch.tensor(np.array([pad(w, NUM_TOKENS) for w in words], dtype="int64"))
 
     def _finish(self, x, vae, args):
         """``train.py:238-250``: latents / 0.18215 -> vae.decode -> [0,1] image (vae is duck-typed)."""
@@ -233,29 +261,34 @@ class Diffusion:
 
     @torch.no_grad()
     def sampling(self, model, vae, n, x_text, labels, args, mix_rate=None, cfg_scale=3, phoscLabels=None,
-                 noise=None, x_T=None, seed=None, sample_offset=0, record=None, use_graph=True):
+                 noise=None, x_T=None, seed=None, sample_offset=0, record=None, use_graph=True, underscore=None):
         """``train.py:200`` signature; extra keyword-only style arguments (phoscLabels, noise, x_T, seed,
         sample_offset) serve the PHOSC variant (``trainGWModifyCondition.py:249``), the parity tests and
-        rank-sharded sampling.  ``vae=None`` returns the denoised latents."""
+        rank-sharded sampling.  ``vae=None`` returns the denoised latents.  ``underscore``: word ids from the 53-class
+        ``'_'`` alphabet of the ModifyCondition scripts (default: when the model's table has the 54 rows that alphabet
+        needs).  Like the reference (``train.py:201,238``) the model is put in eval mode for the loop and in TRAIN mode
+        afterwards, whatever mode it came in."""
         if mix_rate is not None:
             raise NotImplementedError("mix_rate interpolation (unet.py:1558-1573)")
-        was_training = model.training
+        if underscore is None:
+            underscore = int(model.word_emb.embedding.weight.shape[0]) == VOCAB_SIZE_UNDERSCORE
         model.eval()
         device = torch.device(getattr(args, "device", self.device))
         if device.type != "cuda":
             raise N.NativeError("Diffusion.sampling runs on an MI355X only (no CPU fallback)")
         if self.img_size is None or not (getattr(args, "latent", True) == True):  # noqa: E712
             raise NotImplementedError("latent=False")
-        tf = self._text_features(x_text, n)
+        tf = self._text_features(x_text, n, underscore)
         phosc = None
         if getattr(args, "phosc", 0) == 1 or getattr(args, "phos", 0) == 1:
             if phoscLabels is None:
                 raise ValueError("args.phosc/phos set but phoscLabels missing")
             phosc = phoscLabels.int()
-        x = self._denoise(model, n, tf, labels, phosc, device, x_T=x_T, noise=noise, seed=seed,
-                          sample_offset=sample_offset, record=record, use_graph=use_graph)
-        if was_training:
-            model.train()
+        try:
+            x = self._denoise(model, n, tf, labels, phosc, device, x_T=x_T, noise=noise, seed=seed,
+                              sample_offset=sample_offset, record=record, use_graph=use_graph)
+        finally:
+            model.train()  # train.py:238 (unconditional)
         return self._finish(x, vae, args)
 
     sample = sampling  # sampling.py:119 / full_sampling.py:167 call .sample(...)
@@ -280,8 +313,7 @@ class Diffusion:
             raise NotImplementedError("mix_rate interpolation (unet.py:1558-1573)")
         if emaOld == 1:
             model = model1
-        was_training = model.training
-        model.eval()
+        model.eval()  # and it stays in eval mode: ``#model.train()`` is commented out at regenerateFromtrain2.py:622
         device = torch.device(getattr(args, "device", self.device))
         if device.type != "cuda":
             raise N.NativeError("Diffusion.sampling3 runs on an MI355X only (no CPU fallback)")
@@ -289,7 +321,7 @@ class Diffusion:
             word_list = [x_text if isinstance(x_text, str) else x_text[0]] * n
         else:
             word_list = list(words)
-        tf = self._text_features(word_list, n)
+        tf = self._text_features(word_list, n, int(model.word_emb.embedding.weight.shape[0]) == VOCAB_SIZE_UNDERSCORE)
         phosc = None
         if getattr(args, "phosc", 0) == 1 or getattr(args, "phos", 0) == 1:
             if phoscLabels is None:
@@ -301,8 +333,6 @@ class Diffusion:
                           sample_offset=sample_offset, use_graph=use_graph,
                           calls_model=None if full else (lambda i: self.sampling3_calls_model(i, T, epoch)),
                           deterministic=not full)
-        if was_training:
-            model.train()
         if vae is None:
             return x
         image = self._finish(x, vae, args)
@@ -310,8 +340,11 @@ class Diffusion:
 
     def sampling_modify_condition(self, model, vae, latents, x_text, words, n, labels, args, **kw):
         """Argument order of ``trainModifyCondition.py:545``; that variant feeds writer id 1 for every sample
-        (``s_id = torch.ones(...)``, ``:565``) whatever ``labels`` holds."""
+        (``s_id = torch.ones(...)``, ``:565``) whatever ``labels`` holds, reads its word ids from the ``'_'`` alphabet
+        (``:166-180``) and never runs the second forward (``if 0:`` at ``:590``).  Its schedule is the caller's:
+        ``Diffusion()`` of that script defaults to ``noise_steps = 600`` (``:516``) - pass it to the constructor."""
         s_id = torch.ones(n, dtype=torch.int64)
+        kw.setdefault("underscore", True)
         return self.sampling(model, vae, n, x_text, s_id, args, cfg_scale=0, **kw)
 
     def sampling_phosc(self, model, vae, n, x_text, phoscLabels, labels, args, mix_rate=None, cfg_scale=3, **kw):

@@ -54,6 +54,23 @@ def writer_dict(rows: Sequence[Tuple[str, str, str]], path: Optional[str] = None
     return out
 
 
+def make_phosc_of(alphabet_csv: str, version: str = "eng", phosc: int = 1, phos: int = 0):
+    """word -> int64 PHOSC vector (``datasets.py:44-70``) with the reference's shape-count table read from ``alphabet_csv``
+    (``ResPhoSCNetZSL/modules/utils/Alphabet.csv``; a data file of the reference, not shipped here).  One vector per
+    distinct word is computed and kept (the reference recomputes or unpickles a ``wordPhosc`` dictionary,
+    trainModifyCondition.py:268-292)."""
+    from .phosc import load_alphabet, phosc_vector
+    index, table = load_alphabet(alphabet_csv)
+    memo: Dict[str, torch.Tensor] = {}
+
+    def phosc_of(word: str) -> torch.Tensor:
+        if word not in memo:
+            memo[word] = torch.from_numpy(phosc_vector(word, index, table, version, phosc=phosc, phos=phos))
+        return memo[word]
+
+    return phosc_of
+
+
 def write_png(path: str, img: np.ndarray) -> None:
     """uint8 [H, W] (grey) or [H, W, 3] (RGB) -> PNG (zlib-deflated, filter 0 scanlines)."""
     img = np.ascontiguousarray(img)
@@ -130,6 +147,10 @@ def main(argv=None):
     ap.add_argument("--num_res_blocks", type=int, default=1)
     ap.add_argument("--noise_steps", type=int, default=1000)
     ap.add_argument("--phosc", type=int, default=0)
+    ap.add_argument("--alphabet_csv", default=None,
+                    help="--phosc 1: the reference's shape-count table (ResPhoSCNetZSL/modules/utils/Alphabet.csv)")
+    ap.add_argument("--vocab_size", type=int, default=53, choices=[53, 54],
+                    help="53: the 52-letter alphabet of train.py; 54: the '_' alphabet of trainModifyCondition.py:68")
     ap.add_argument("--skip_steps", type=int, default=0, help="1: regenerateFromtrain2.py's step-skipping sampler")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stable_dif_path", default=None,
@@ -146,7 +167,7 @@ def main(argv=None):
     cls = UNetModelPhosc if a.phosc else UNetModel
     unet = cls(image_size=(64, 256), in_channels=4, model_channels=a.emb_dim, out_channels=4, num_res_blocks=a.num_res_blocks,
                attention_resolutions=(1, 1), channel_mult=(1, 1), num_heads=a.num_heads, num_classes=max(339, len(wr)),
-               context_dim=a.emb_dim, vocab_size=53, args=args, max_seq_len=10).to(dev)
+               context_dim=a.emb_dim, vocab_size=a.vocab_size, args=args, max_seq_len=10).to(dev)
     if a.models_path:
         unet.load_state_dict(torch.load(os.path.join(a.models_path, "models", "ema_ckpt.pt"), map_location=dev,
                                         weights_only=True))
@@ -156,8 +177,14 @@ def main(argv=None):
     if a.stable_dif_path:
         from .vae import AutoencoderKL
         vae = AutoencoderKL.from_pretrained(a.stable_dif_path, subfolder="vae").to(dev)
+    phosc_of = None
+    if a.phosc:
+        if not a.alphabet_csv:
+            ap.error("--phosc 1 needs --alphabet_csv (the PHOS shape-count table)")
+        phosc_of = make_phosc_of(a.alphabet_csv)
     start, res = regenerate(ema_model, diffusion, rows, wr, args, vae=vae, batch=a.batch_size,
-                            out_dir=os.path.join(a.save_path, "images"), seed=a.seed, skip_steps=bool(a.skip_steps))
+                            out_dir=os.path.join(a.save_path, "images"), seed=a.seed, skip_steps=bool(a.skip_steps),
+                            phosc_of=phosc_of)
     print(f"[rank {rank}/{world}] rows {start}..{start + len(res)} of {len(rows)} written to {a.save_path}/images")
 
 

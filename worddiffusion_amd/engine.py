@@ -109,6 +109,18 @@ def slab_span(tab: Optional[np.ndarray], hw_out: int, hw_src: int, m: int, bm: i
     return span
 
 
+_PARAM_GEN = [0]  # bumped whenever any nn.Module registers a Parameter (see UNetEngine._signature)
+
+
+def _bump_param_gen(*_a):
+    _PARAM_GEN[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_param_gen)
+
+FILM_CHUNK_ROWS = int(os.environ.get("WDIFF_FILM_CHUNK_ROWS", "8192"))  # rows (timesteps x batch) of the resident FiLM chunk
+
+
 class _Recipe:
     __slots__ = ("name", "planes", "rows", "cols", "shape", "pieces")
 
@@ -239,7 +251,14 @@ class Plan:
         self._run(self.cond, stream)
 
     def run_film(self, stream):
+        """Per-call part of the tabulated FiLM path: the time MLP of every timestep.  The chunk of the table a step reads is
+        brought in by ``film_prepare(t, stream)`` (a no-op closure when the plan has no table)."""
         self._run(getattr(self, "film", []), stream)
+        self.film_loaded = -1  # writer ids / weights may have changed since the last call: no chunk is valid
+
+    @staticmethod
+    def film_prepare(t, stream):
+        return False
 
     def run_step(self, stream):
         self._run(self.step, stream)
@@ -258,6 +277,7 @@ class UNetEngine:
         self.lib = N.lib()
         self.npass = 3
         self._sig = None
+        self._ps, self._ps_gen = None, -1
         self._pack = None
         self._w: Dict[str, torch.Tensor] = {}
         self._w3: Dict[str, torch.Tensor] = {}      # slab-order copies of the matrices the v3 kernel consumes
@@ -406,7 +426,11 @@ class UNetEngine:
                 yield f"out{i}.{j}", mod
 
     def _signature(self):
-        ps = list(self.model.parameters())
+        # the module-tree walk of ``model.parameters()`` costs ~0.35 ms for the 264 tensors, 10x the rest of this function:
+        # the list is kept until some module of the process registers a Parameter (object identity can only change then)
+        if self._ps is None or self._ps_gen != _PARAM_GEN[0]:
+            self._ps, self._ps_gen = list(self.model.parameters()), _PARAM_GEN[0]
+        ps = self._ps
         return (sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), str(ps[0].device))
 
     def refresh_weights(self, force: bool = False):
@@ -848,27 +872,50 @@ class UNetEngine:
         P.t_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         P.film = []
         if film_steps:
+            # the table holds ``chunk`` consecutive timesteps (rows (t % chunk) * B + b), not all T: T*B*film_total fp32 was
+            # 655 MB + 328 MB of operand planes at B = 64 and grew with B and T; a chunk of ~8192 rows is 84 + 42 MB at any
+            # B.  The time MLP (T rows, cheap) is still evaluated for every t once per call (P.film); the SiLU(time + label)
+            # planes and the emb_layers GEMM of a chunk run when the loop enters it (P.film_prepare, same stream, a fraction
+            # of one step each).
             T = film_steps
+            chunk = min(T, max(8, FILM_CHUNK_ROWS // B))
+            nchunks = (T + chunk - 1) // chunk
+            Tp = nchunks * chunk
             film = P.film
-            tt = torch.arange(T, dtype=torch.int64, device=dev)
+            tt = torch.arange(Tp, dtype=torch.int64, device=dev)
             P.keep.append(tt)
-            te = self._planes(P, T, mc)
-            film.append((lib.wd_timestep_embedding, (tt.data_ptr(), T, self._w["freqs"].data_ptr(), mc // 2, te[0].data_ptr(),
+            te = self._planes(P, Tp, mc)
+            film.append((lib.wd_timestep_embedding, (tt.data_ptr(), Tp, self._w["freqs"].data_ptr(), mc // 2, te[0].data_ptr(),
                                                      te[1].data_ptr() if lo_ok else None, mc), "timestep_embedding[all t]"))
-            e1 = self._planes(P, T, ted)
-            self._gemm(film, "time_embed.0[all t]", [self._src(te, mc)], "te0.w", T, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
+            e1 = self._planes(P, Tp, ted)
+            self._gemm(film, "time_embed.0[all t]", [self._src(te, mc)], "te0.w", Tp, 1, bias=self._w["te0.b"], act=N.ACT_SILU,
                        out_pl=e1)
-            tm = self._f32(P, T, ted)
-            self._gemm(film, "time_embed.2[all t]", [self._src(e1, ted)], "te2.w", T, 1, bias=self._w["te2.b"], out_f32=tm,
+            tm = self._f32(P, Tp, ted)
+            self._gemm(film, "time_embed.2[all t]", [self._src(e1, ted)], "te2.w", Tp, 1, bias=self._w["te2.b"], out_f32=tm,
                        out_ld=ted)
-            e2 = self._planes(P, T * B, ted)
-            film.append((lib.wd_emb_combine, (tm.data_ptr(), self._w["label"].data_ptr() if has_lab else None,
-                                              P.y_in.data_ptr() if has_lab else None, T, B, ted, e2[0].data_ptr(),
-                                              e2[1].data_ptr() if lo_ok else None, ted), "SiLU(time + label)[all t]"))
-            P.film_table = self._f32(P, T * B, self.film_total)
-            self._gemm(film, "emb_layers(all)[all t]", [self._src(e2, ted)], "film.w", T * B, 1, bias=self._w["film.b"],
-                       out_f32=P.film_table, out_ld=self.film_total)
-            step.append((lib.wd_select_rows, (P.film_table.data_ptr(), P.t_dev.data_ptr(), B, self.film_total,
+            e2 = self._planes(P, chunk * B, ted)
+            P.film_table = self._f32(P, chunk * B, self.film_total)
+            P.film_chunk, P.film_nchunks, P.film_loaded = chunk, nchunks, -1
+            chunk_gemm = []
+            self._gemm(chunk_gemm, "emb_layers(all)[chunk of t]", [self._src(e2, ted)], "film.w", chunk * B, 1,
+                       bias=self._w["film.b"], out_f32=P.film_table, out_ld=self.film_total)
+            lab = self._w["label"].data_ptr() if has_lab else None
+            yin = P.y_in.data_ptr() if has_lab else None
+            ncls = m.num_classes if has_lab else 0
+
+            def film_prepare(t, stream, P=P, tm=tm, e2=e2, chunk=chunk, B=B):
+                """Makes the FiLM rows of timestep ``t`` resident: (re)computes the chunk ``t // chunk`` unless it is loaded."""
+                c = int(t) // chunk
+                if c == P.film_loaded:
+                    return False
+                N.check(lib.wd_emb_combine(tm.data_ptr() + 4 * c * chunk * ted, lab, yin, ncls, chunk, B, ted, e2[0].data_ptr(),
+                                           e2[1].data_ptr() if lo_ok else None, ted, stream), "SiLU(time + label)[chunk of t]")
+                Plan._run(chunk_gemm, stream)
+                P.film_loaded = c
+                return True
+
+            P.film_prepare = film_prepare
+            step.append((lib.wd_select_rows, (P.film_table.data_ptr(), P.t_dev.data_ptr(), B, self.film_total, chunk,
                                               self._film.data_ptr()), "film rows of step t"))
         else:
             te = self._planes(P, B, mc)
@@ -947,7 +994,34 @@ class UNetEngine:
         return P
 
     # ------------------------------------------------------------------------------------------ run
-    def load_inputs(self, P: Plan, x=None, t=None, context=None, y=None, phosc=None):
+    def check_ids(self, context=None, y=None, phosc=None, need_y=True):
+        """Host-side range check of every integer the kernels use as a table row: writer ids against ``num_classes``
+        (``label_emb``, unet.py:1581), word / PHOSC ids against the rows of the character table (unet.py:860).  The
+        reference raises an index error for such an id; a raw device read past the table could fault the GPU instead."""
+        m = self.model
+        vocab = int(m.word_emb.embedding.weight.shape[0]) if hasattr(m, "word_emb") else None
+        checks = []
+        if getattr(m, "num_classes", None) is not None:
+            if y is None:
+                if need_y:
+                    raise ValueError("y (writer ids) is required: the model is class-conditional (unet.py:1555)")
+            else:
+                checks.append(("writer id (y)", y, m.num_classes))
+        for what, ids in (("word id (context)", context), ("PHOSC id (phoscLabels)", phosc)):
+            if ids is not None and vocab is not None and ids.numel():
+                checks.append((what, ids, vocab))
+        if not checks:
+            return
+        vals = [v for _, ids, _ in checks for v in (ids.min().long(), ids.max().long())]
+        ext = torch.stack(vals).tolist() if len({v.device for v in vals}) == 1 else [int(v) for v in vals]  # one sync
+        for i, (what, _, bound) in enumerate(checks):
+            lo, hi = int(ext[2 * i]), int(ext[2 * i + 1])
+            if lo < 0 or hi >= bound:
+                raise IndexError(f"{what} out of range: [{lo}, {hi}] does not fit a table of {bound} rows")
+
+    def load_inputs(self, P: Plan, x=None, t=None, context=None, y=None, phosc=None, check=True):
+        if check:
+            self.check_ids(context, y, phosc, need_y=False)
         if x is not None:
             P.x_in.copy_(x, non_blocking=True)
         if t is not None:
@@ -965,7 +1039,8 @@ class UNetEngine:
         ctx_len = 0 if context is None else context.shape[1]
         phosc_len = 0 if phosc is None else phosc.shape[1]
         P = self.plan(B, H, W, ctx_len, phosc_len)
-        self.load_inputs(P, x, t, context, y, phosc)
+        self.check_ids(context, y, phosc)
+        self.load_inputs(P, x, t, context, y, phosc, check=False)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         P.run_cond(stream)
         P.run_step(stream)

@@ -48,10 +48,18 @@ class UNetBase(nn.Module):
             raise NotImplementedError("n_embed (codebook id prediction) is not on the accelerated path")
         if isinstance(context_dim, (list, tuple)):
             context_dim = list(context_dim)[0]
-        for flag in ("charImages", "attentionMaps", "ocrTraining", "wrdChrWrStyl", "charLevelEmb"):
+        for flag in ("charImages", "attentionMaps", "ocrTraining", "wrdChrWrStyl"):
             if _arg(args, flag, 0):
                 raise NotImplementedError(f"args.{flag}=1 selects an auxiliary head / debugging output that is "
                                           "outside the accelerated denoising path (SURVEY.md 8b)")
+        # args.charLevelEmb=1 (the default of unet.py:1871; checkpoints ``ckpt_ema_charLevelEmb.pt``, config.py:61): the base
+        # CharacterEncoder flattens the ids, embeds them and views the result back as (B, 10, 320) (unet.py:855-864) - the same
+        # tensor as without the flag (tests/golden/fwd_base_full_charlevel.npz: bit-identical output).  The view hard-codes
+        # 10 tokens x 320 channels, so the reference itself fails for any other context width.  unetPhosc.py never reads it.
+        self.char_level_emb = bool(_arg(args, "charLevelEmb", 0)) and self.variant == "base"
+        if self.char_level_emb and context_dim != 320:
+            raise NotImplementedError("args.charLevelEmb=1 needs context_dim=320: unet.py:864 views the embedding as "
+                                      "(B, 10, 320) and raises for any other width")
         if num_heads == -1 and num_head_channels == -1:
             raise AssertionError("Either num_heads or num_head_channels has to be set")
         if num_heads_upsample == -1:
@@ -185,6 +193,10 @@ class UNetBase(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"x must be [B,{self.in_channels},H,W], got {tuple(x.shape)}")
 
+    def _check_context(self, context):
+        if self.char_level_emb and context is not None and context.shape[1] != 10:
+            raise ValueError("args.charLevelEmb=1: context must be [B, 10] (unet.py:864 views the embedding as (B, 10, 320))")
+
     @property
     def train_engine(self):
         """Forward-with-saved-intermediates + backward launch lists (``train_engine.py``); base variant only."""
@@ -197,7 +209,7 @@ class UNetBase(nn.Module):
         return self._train_engine
 
     def _run(self, x, timesteps, context, y, phosc=None):
-        if torch.is_grad_enabled() and self.training:
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             # ``predicted_noise = model(...)`` inside the training loop (train.py:287): the result carries a grad_fn whose
             # backward runs the HIP backward list and fills ``param.grad`` (reference layouts), so ``loss.backward()``,
             # ``optimizer.step()`` and ``ema.step_ema`` of the reference loop work unchanged.

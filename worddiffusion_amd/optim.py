@@ -38,7 +38,10 @@ class FusedAdamW:
         self.params = [p for p in params]
         if not self.params or not self.params[0].is_cuda:
             raise N.NativeError("FusedAdamW needs CUDA parameters (no CPU fallback)")
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # one group in torch.optim's layout: the source of truth for the hyper-parameters (LR schedulers write ``lr`` here)
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                  params=self.params)]
         self.ema_params = list(ema_model.parameters()) if ema_model is not None else None
         if self.ema_params is not None and len(self.ema_params) != len(self.params):
             raise ValueError("ema_model does not match the parameter list")
@@ -49,10 +52,64 @@ class FusedAdamW:
         self._table = None
         self._grads = None
         self._grad_ptrs = None
+        self._has_state = [False] * len(self.params)  # parameters that have been stepped (torch keeps state only for those)
 
-    def zero_grad(self):
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
+    def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
-            p.grad = None
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    # ---- checkpointing: ``torch.save(optimizer.state_dict(), "models/optim.pt")`` (train.py:316) / resume -------------------
+    def state_dict(self):
+        """``torch.optim.AdamW.state_dict()`` layout - ``state[i] = {step, exp_avg, exp_avg_sq}`` for every parameter that has
+        received a gradient, ``param_groups`` with parameter indices - so the file loads into either optimiser.  The extra
+        ``wdiff`` entry (ignored by torch) carries the step counter that also positions the EMA warm-up."""
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self.params):
+                if not self._has_state[i]:
+                    continue  # never stepped (no gradient): torch.optim.AdamW holds no state for it either
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[i].clone(),
+                                exp_avg_sq=self.exp_avg_sq[i].clone())
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return dict(state=state, param_groups=[group],
+                    wdiff=dict(step_count=self.step_count, ema_beta=self.ema_beta, step_start_ema=self.step_start_ema))
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        for k, v in groups[0].items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v
+        steps = set()
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                self._has_state[i] = st is not None
+                if st is None:
+                    self.exp_avg[i].zero_()
+                    self.exp_avg_sq[i].zero_()
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+                self.exp_avg[i].copy_(st["exp_avg"])
+                self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one fused launch uses one bias correction")
+        extra = sd.get("wdiff", {})
+        self.step_count = int(extra.get("step_count", steps.pop() if steps else 0))
+        self.ema_beta = extra.get("ema_beta", self.ema_beta)
+        self.step_start_ema = extra.get("step_start_ema", self.step_start_ema)
 
     def _build_table(self):
         lib = N.lib()
@@ -71,6 +128,7 @@ class FusedAdamW:
         self._table = raw.to(self.params[0].device)
         self._chunks = c0
         self._grad_ptrs = [g.data_ptr() if g is not None else 0 for g in self._grads]
+        self._has_state = [h or g is not None for h, g in zip(self._has_state, self._grads)]
 
     def step(self):
         lib = N.lib()

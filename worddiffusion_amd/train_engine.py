@@ -949,6 +949,7 @@ class TrainEngine(UNetEngine):
         B, _, H, W = x.shape
         if context is None:
             raise NotImplementedError("context=None")
+        self.check_ids(context, y, phosc)
         P = self.plan_train(B, H, W, context.shape[1], 0 if phosc is None else phosc.shape[1])
         P.x_in.copy_(x, non_blocking=True)
         P.t_in.copy_(t, non_blocking=True)

@@ -32,9 +32,15 @@ class TrainStep:
         self._key = None
         self._graph = None
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+        # data-parallel ranks must not draw the same (eps, t): the noise rows are keyed by the GLOBAL row of the step
+        # (``(step * world + rank) * B + b``, so world ranks of batch B draw what one process of batch world*B would), and the
+        # timesteps come from a per-rank host generator (a single process keeps the reference's global host RNG, train.py:281)
+        self._tgen = torch.Generator().manual_seed((int(seed) * 1000003 + self.rank) & 0x7FFFFFFFFFFFFFFF) if self.world > 1 \
+            else None
 
     def _prepare(self, B, H, W, L, dev, phosc_len=0):
         eng = self.eng
@@ -78,8 +84,12 @@ class TrainStep:
             self._prepare(B, H, W, text_features.shape[1], dev, phosc_len)
             self._key = key
         lib, P = self.lib, self._P
+        self.eng.check_ids(text_features, labels, phoscLabels)  # out-of-range ids raise here instead of faulting a kernel
         if t is None:
-            t = self.diffusion.sample_timesteps(B)  # host RNG like the reference (train.py:281)
+            if self._tgen is None:
+                t = self.diffusion.sample_timesteps(B)  # host RNG like the reference (train.py:281)
+            else:
+                t = torch.randint(low=1, high=self.diffusion.noise_steps, size=(B,), generator=self._tgen)
         # the legacy default stream cannot be captured: the step runs on its own stream, ordered after the caller's work
         # and before whatever the caller enqueues next
         cur = torch.cuda.current_stream(dev)
@@ -97,8 +107,8 @@ class TrainStep:
             if noise is not None:
                 self._eps.copy_(noise, non_blocking=True)
             else:
-                N.check(lib.wd_randn(self._eps.data_ptr(), B, self._eps[0].numel(), self.seed, self.step_index * B, 2, st),
-                        "wd_randn")
+                N.check(lib.wd_randn(self._eps.data_ptr(), B, self._eps[0].numel(), self.seed,
+                                     (self.step_index * self.world + self.rank) * B, 2, st), "wd_randn")
             if self.use_graph:
                 if self._graph is None:
                     N.check(lib.wd_graph_begin(st), "wd_graph_begin")

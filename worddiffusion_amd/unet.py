@@ -30,6 +30,7 @@ class UNetModel(UNetBase):
                 charContextImages=None, original_context=None, or_images=None, mix_rate=None, **kwargs):
         """Predicted noise [B, out_channels, H, W] (``unet.py:1499``; returns ``h`` as at ``:1821/:1836``)."""
         self._check_common(x, timesteps, mix_rate)
+        self._check_context(context)
         if self.num_classes is not None:
             if _arg(self.args, "imgConditioned", 0) == 1:
                 raise NotImplementedError("args.imgConditioned=1 drops the writer embedding (unet.py:1578-1579)")
