@@ -98,6 +98,12 @@ typedef struct wd_gemm_args {
     int32_t stat_cpg;     /* channels per statistics group */
     int32_t dbg;          /* 0 in production.  0x400: take the two-workgroups-per-CU kernel (wd_gemm4_kernel) wherever it is
                              legal, whatever the grid size (parity tests); other bits are timing experiments */
+    int32_t* tickets;     /* NULL: split-K partials are combined by a second launch.  Else ntickets ints, ALL ZERO before the
+                           * call and left all zero by it, not shared with a launch that may run concurrently: one arrival
+                           * counter per output tile - the workgroup that finishes a tile's last K slice sums the slices from
+                           * ws in ascending slice order and runs the epilogue itself (same bits as the second launch, one
+                           * launch less).  Used when the shapes allow it (16-byte aligned operands, n a multiple of the tile) */
+    int32_t ntickets;
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);

@@ -38,7 +38,7 @@ SLAB = [False, True]
 
 
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0, dbg=0):
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0, dbg=0, tickets=None):
     """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
     slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
@@ -87,6 +87,8 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
         ws = torch.empty(max(ksplit, 8) * m * n, device=DEV)
         keep.append(ws)
         args.ws, args.ws_floats = ws.data_ptr(), ws.numel()
+    if tickets is not None:  # in-launch split-K combine: zeroed arrival counters, left zeroed
+        args.tickets, args.ntickets = tickets.data_ptr(), tickets.numel()
     N.check(lib.wd_gemm(C.byref(args), _st()), "wd_gemm")
     torch.cuda.synchronize()
     return out, opl
@@ -207,6 +209,14 @@ def test_gemm_split_k(ksplit):
     out2, _ = run_gemm(srcs, wcat.to(DEV), m, hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV),
                        ksplit=ksplit)
     assert torch.equal(out, out2)  # deterministic
+    # the in-launch combine (arrival tickets; the last workgroup of a tile sums the slabs in slice order inside the epilogue)
+    # gives the same bits as the separate combine launch, whichever slice arrives last, and leaves its counters zeroed
+    tk = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    for _ in range(3):
+        out3, pl3 = run_gemm(srcs, wcat.to(DEV), m, hw, bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV),
+                             want_planes=True, ksplit=ksplit, tickets=tk, dbg=0x2000)
+        assert torch.equal(out3, out) and torch.equal(pl3, pl)
+        assert int(tk.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("B,hh,ww,c1,c2,n,ksplit", [(4, 4, 16, 320, 640, 320, 1), (3, 8, 32, 64, 0, 160, 1), (5, 5, 7, 128, 64, 200, 1),
@@ -233,6 +243,53 @@ def test_gemm_two_workgroups_per_cu_kernel(B, hh, ww, c1, c2, n, ksplit):
     assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
     out0, _ = run_gemm(srcs, wcat.to(DEV), m, hw, **kw)
     assert max_rel(out.cpu(), out0.cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("B,hh,ww,c1,c2,n,ksplit,npass", [(4, 4, 16, 320, 640, 320, 1, 3), (3, 8, 32, 64, 0, 160, 1, 3), (5, 5, 7, 128, 64, 200, 1, 3),
+                                                            (4, 4, 16, 320, 640, 320, 3, 3), (64, 8, 32, 64, 0, 320, 1, 3), (2, 8, 32, 32, 0, 320, 1, 3),
+                                                            (3, 8, 32, 96, 32, 160, 2, 1), (64, 8, 32, 320, 0, 320, 1, 3)])
+@pytest.mark.parametrize("sel", [0x80000])
+def test_gemm_deep_pipeline_kernel(B, hh, ww, c1, c2, n, ksplit, npass, sel):
+    """wd_gemm8_kernel (dbg 0x80000 forces it): 32-deep stages in a ring of four LDS buffers, counted vmcnt, four dedicated loader
+    waves + eight compute waves with two fragment sets -
+    3x3 gather source + optional identity skip source, FiLM row vector, residual, planes out, ragged M / N, split-K, short K loops
+    (1 .. 3 stages: the prologue / drain paths), single-pass bf16 - vs fp64 and vs the v2 kernel; repeated launches give the same bits
+    (a race between the LDS-DMA ring and the fragment reads would not)."""
+    g = torch.Generator().manual_seed(B + hh + ww + c1 + n)
+    hw, m = hh * ww, B * hh * ww
+    a1 = torch.randn(m, c1, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    wcat = torch.randn(n, 9 * c1 + c2, generator=g) / (9 * c1 + c2) ** 0.5
+    bias, film, res = torch.randn(n, generator=g), torch.randn(B, n, generator=g), torch.randn(m, n, generator=g)
+    x1 = a1.reshape(B, hh, ww, c1).permute(0, 3, 1, 2)
+    ref = (F.conv2d(x1.double(), wcat[:, :9 * c1].reshape(n, 3, 3, c1).permute(0, 3, 1, 2).double(), padding=1)
+           .permute(0, 2, 3, 1).reshape(m, n) + bias.double() + film.double().repeat_interleave(hw, 0) + res.double())
+    srcs = [(planes_of(a1.to(DEV)), c1, 9, torch.from_numpy(tab).to(DEV), hw)]
+    if c2:
+        a2 = torch.randn(m, c2, generator=g)
+        ref = ref + a2.double() @ wcat[:, 9 * c1:].double().t()
+        srcs.append((planes_of(a2.to(DEV)), c2, 1, None, 0))
+    tol = 2e-5 if npass == 3 else 2e-2
+    kw = dict(bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV), want_planes=True, ksplit=ksplit, tile=128160, npass=npass)
+    out, pl = run_gemm(srcs, wcat.to(DEV), m, hw, dbg=sel, **kw)
+    assert rel_err(out.cpu(), ref) < tol and rel_err(unplanes(pl).cpu(), ref) < tol
+    if c1 % 64 == 0 and c2 % 64 == 0:
+        out0, _ = run_gemm(srcs, wcat.to(DEV), m, hw, **kw)
+        assert max_rel(out.cpu(), out0.cpu()) < (5e-6 if npass == 3 else 2e-2)
+    for _ in range(5):
+        out2, pl2 = run_gemm(srcs, wcat.to(DEV), m, hw, dbg=sel, **kw)
+        assert torch.equal(out, out2) and torch.equal(pl, pl2)
+
+
+@pytest.mark.parametrize("k,sel", [(32, 0x80000), (64, 0x80000), (96, 0x80000), (128, 0x80000), (160, 0x80000), (320, 0x80000)])
+def test_gemm_deep_pipeline_kernel_short_loops(k, sel):
+    """1 .. 10 stages of a plain linear through wd_gemm8_kernel: every length of the prologue / steady state / drain."""
+    g = torch.Generator().manual_seed(k)
+    m, n = 300, 320
+    a, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    out, _ = run_gemm([(planes_of(a.to(DEV)), k, 1, None, 0)], w.to(DEV), m, 1, bias=b.to(DEV), tile=128160, dbg=sel)
+    assert rel_err(out.cpu(), ref) < 2e-5
 
 
 def test_gemm_two_workgroups_per_cu_kernel_geglu():
@@ -330,6 +387,17 @@ def test_gemm_fused_groupnorm_statistics(B, hh, ww, cin, n, ksplit):
     lib_args.ksplit, lib_args.ws, lib_args.ws_floats = ksplit, ws.data_ptr(), ws.numel()
     N.check(lib.wd_gemm(C.byref(lib_args), _st()), "wd_gemm+stats")
     torch.cuda.synchronize()
+    if ksplit != 1:  # the same launch with the in-launch split-K combine: identical output and statistics
+        out_sep, part_sep = out.clone(), part.clone()
+        tk = torch.zeros(1024, dtype=torch.int32, device=DEV)
+        lib_args.tickets, lib_args.ntickets, lib_args.dbg = tk.data_ptr(), tk.numel(), 0x2000
+        out.zero_()
+        part.fill_(float("nan"))
+        N.check(lib.wd_gemm(C.byref(lib_args), _st()), "wd_gemm+stats+tickets")
+        torch.cuda.synchronize()
+        # (same output bits; the statistics are fixed-order sums over a different tile shape - 128 x 160 here, 64 x 40 in the
+        # combine launch - so they agree to fp32 rounding of the per-thread column sums, not bit for bit)
+        assert torch.equal(out, out_sep) and max_rel(part, part_sep) < 1e-5 and int(tk.abs().sum()) == 0
     o = out.cpu().double().reshape(B, hw, 32, cpg)
     ref_sum = o.sum(dim=(1, 3))
     ref_sq = (o * o).sum(dim=(1, 3))
@@ -607,10 +675,11 @@ def test_folded_cross_attention_pair():
 @pytest.mark.parametrize("B,h,w,cin,cout,skip,ksplit", [(3, 8, 32, 64, 160, 0, 1), (2, 8, 32, 128, 320, 64, 1), (3, 5, 7, 64, 96, 0, 1),
                                                           (5, 4, 16, 64, 320, 128, 0), (2, 3, 200, 64, 64, 0, 1),
                                                           (64, 8, 32, 320, 320, 0, 1)])
-def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit):
-    """wd_gemm with w_layout 2 (wd_conv3_kernel: the three taps of a kernel row share one A tile, 16x16x32 MFMA, stagger) vs
-    F.conv2d (+ 1x1 skip over a second source), incl. panels that straddle samples, narrow / wide images, split-K, and the
-    headline shape."""
+@pytest.mark.parametrize("form", [0x1000])
+def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit, form):
+    """wd_gemm with w_layout 2 (wd_conv3_kernel, forced by dbg 0x1000: the three taps of a kernel row share one A tile, 16x16x32 MFMA,
+    stagger) vs F.conv2d (+ 1x1 skip over a second source), incl. panels that straddle samples, narrow / wide images, split-K, and
+    the headline shape."""
     g = torch.Generator().manual_seed(B * 100 + h * 10 + w + cin)
     x = torch.randn(B, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
@@ -627,9 +696,11 @@ def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit):
         ref = ref + F.conv2d(x2.double(), ws.double()[:, :, None, None])
         a_list.append((planes_of(x2.permute(0, 2, 3, 1).reshape(m, skip).contiguous().to(DEV)), skip, 1, None, 0))
         wp = torch.cat([wp, ws], 1)
-    out, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), same_w=w, ksplit=ksplit)
+    out, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), same_w=w, ksplit=ksplit, dbg=form)
     got = out.cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     assert max_rel(got, ref) < 2e-5
+    out_again, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), same_w=w, ksplit=ksplit, dbg=form)
+    assert torch.equal(out, out_again)
     # same result as the generic kernel up to summation order
     out0, _ = run_gemm(a_list, wp.to(DEV), m, hw, bias=b.to(DEV), ksplit=ksplit)
     assert max_rel(out.cpu(), out0.cpu()) < 5e-6

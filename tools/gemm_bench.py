@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--slab", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--ksplit", type=int, default=1)
+    ap.add_argument("--tickets", type=int, default=0, help="1: in-launch split-K combine (arrival tickets) instead of the combine launch")
+    ap.add_argument("--batch", type=int, default=0, help="batch size (default: the module's B)")
     ap.add_argument("--conv3", type=int, default=0, help="1: row-shared-taps kernel for the 3x3 shapes (w_layout 2)")
     ap.add_argument("--stamps", type=int, default=0, help="1: per-stage cycle stamps of workgroup 0 (s_memtime)")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
@@ -82,8 +84,13 @@ def main():
         ws = torch.empty(8 * m * cout if a.ksplit != 1 and m * cout * 8 < 2 ** 28 else 1, device=DEV)
         if a.ksplit != 1:
             g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
+        tk = torch.zeros(8192, dtype=torch.int32, device=DEV)
+        if a.tickets:
+            g.tickets, g.ntickets = tk.data_ptr(), tk.numel()
+            g.dbg = g.dbg | 0x2000
         if a.conv3 and kind == "conv3":
             g.w_layout, g.slab_rows = 2, w
+            g.dbg = a.dbg | 0x1000
         if a.stamps:
             nk = ktot // 64
             sb = torch.zeros(8 * nk * 4, dtype=torch.int64, device=DEV)

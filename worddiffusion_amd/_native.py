@@ -37,7 +37,8 @@ class WdGemmArgs(C.Structure):
                 ("resid_rows", _vp), ("act", C.c_int32), ("out_f32", _vp), ("out_ld", C.c_int32),
                 ("out_hi", _vp), ("out_lo", _vp), ("out_pl_ld", C.c_int32), ("tile", C.c_int32),
                 ("w_layout", C.c_int32), ("slab_rows", C.c_int32), ("ksplit", C.c_int32), ("ws", _vp),
-                ("ws_floats", C.c_int64), ("stat_part", _vp), ("stat_cpg", C.c_int32), ("dbg", C.c_int32)]
+                ("ws_floats", C.c_int64), ("stat_part", _vp), ("stat_cpg", C.c_int32), ("dbg", C.c_int32),
+                ("tickets", _vp), ("ntickets", C.c_int32)]
 
 
 _SIGS = {

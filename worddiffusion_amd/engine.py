@@ -571,9 +571,25 @@ class UNetEngine:
         if self._ws is None:
             self._ws = torch.empty(128 * 128 * 160 * 8, dtype=torch.float32, device=self.device)  # 84 MB split-K scratch
         a.ksplit, a.ws, a.ws_floats = 0, self._ws.data_ptr(), self._ws.numel()
+        self._give_tickets(a, m, nrows)
         self._cur_plan.keep.append(a)
         ops.append((self.lib.wd_gemm, (C.byref(a),), what))
         return a
+
+    def _give_tickets(self, a, m, n):
+        """Arrival counters for the in-launch split-K combine of one wd_gemm launch: a range of its own inside a zeroed
+        per-plan buffer (zero before and after every launch; only small grids ever split, so only they get one)."""
+        ntick = ((m + 63) // 64) * ((n + 63) // 64)
+        if ntick > 2048:
+            return
+        P = self._cur_plan
+        tk = getattr(P, "_tickets", None)
+        if tk is None or P._ticket_off + ntick > tk.numel():
+            tk = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)
+            P.keep.append(tk)
+            P._tickets, P._ticket_off = tk, 0
+        a.tickets, a.ntickets = tk.data_ptr() + 4 * P._ticket_off, ntick
+        P._ticket_off += ntick
 
     def _gn(self, P, ops, what, srcs: List[Act], gname, eps, silu, want_raw=False):
         """GroupNorm over the channel concat of ``srcs`` -> planes [M, sum c] (+ raw planes)."""

@@ -267,6 +267,7 @@ class TrainEngine(UNetEngine):
         if acc:
             a.resid, a.resid_ld = out.data_ptr(), out_ld
         a.ksplit, a.ws, a.ws_floats = 0, self._ws.data_ptr(), self._ws.numel()
+        self._give_tickets(a, nrows, ncols)
         self._cur_plan.keep.append(a)
         ops.append((self.lib.wd_gemm, (C.byref(a),), what))
 
