@@ -469,14 +469,15 @@ def main():
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/, per round)
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "r01_pmc_hbm_traffic.json")))
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            name = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json"))[-1]  # the latest round's
+            pmc = json.load(open(os.path.join(pdir, name)))
             k = pmc["wd_gemm2_kernel<128, 160, 3, 2, false, true>"]
             traffic = (k["fetch_mb_corrected"] + k["write_mb"]) * 1e6
             traffic_note = ("HBM bytes per launch of wd_gemm2_kernel<128,160,3,2,M16> (its 256-workgroup launches): %.1f MB fetched (FETCH_SIZE, gfx950 x2 "
                             "correction) + %.1f MB written (WRITE_SIZE); separate rocprofv3 --pmc passes over this bench "
-                            "command, profiles/r01_pmc_hbm_traffic.json" % (k["fetch_mb_corrected"], k["write_mb"]))
-        except (OSError, KeyError, ValueError):
+                            "command, profiles/%s" % (k["fetch_mb_corrected"], k["write_mb"], name))
+        except (OSError, KeyError, ValueError, IndexError):
             traffic, traffic_note = None, "no PMC summary under profiles/"
         roof = dict(bound="mfma", kernel="wd_gemm2_kernel<128,160,3,2> (tap-gather split-bf16 MFMA GEMM: the 3x3 convolutions, "
                                          "1x1 / linear projections and GEGLU of the step; hipEvent pair around every launch)",

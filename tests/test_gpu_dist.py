@@ -114,3 +114,47 @@ def test_bench_gpus_2_runs_two_ranks_and_reports_them():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["batch_per_gpu"] == 8
     assert line["value"] > 0 and line["config"]["output_finite"]
+
+
+def test_bucketed_backward_equals_single_graph_and_covers_the_arena():
+    """The data-parallel form of TrainStep cuts the backward list into segments after each of which a prefix of the gradient
+    arena is final (all-reduced while the next segment runs).  Single process: the segmented step must give the same bits as
+    the one-graph step; the segments must tile the backward list and the arena; and a gradient must not change after the
+    segment that declares it final (checked by running the segments one at a time and snapshotting the prefix)."""
+    import copy
+    m1, _, opt1, diff, TrainStep = _setup(31)
+    m2, _, opt2, _, _ = _setup(31)
+    inp, eps = _batch(8)
+    dev = "cuda:0"
+    s1 = TrainStep(m1, diff, opt1)
+    s2 = TrainStep(m2, diff, opt2, bucketed=True)
+    for _ in range(2):
+        l1 = s1(inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev), t=inp["t"], noise=eps.to(dev))
+        l2 = s2(inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev), t=inp["t"], noise=eps.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2)
+    for (k, a), b in zip(m1.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+    segs = s2.segments
+    assert len(segs) == 3 and not s1.segments
+    P = s2._P
+    assert segs[0][0] == 0 and segs[-1][1] == len(P.bwd) and all(segs[i][1] == segs[i + 1][0] for i in range(len(segs) - 1))
+    used = s2.eng.grad_arena().numel()
+    assert segs[0][2] == 0 and segs[-1][3] == used and all(segs[i][3] == segs[i + 1][2] for i in range(len(segs) - 1))
+    sizes = [s[3] - s[2] for s in segs]
+    assert min(sizes[:2]) > used // 8, sizes  # the first two buckets carry a real share of the bytes (overlap is worth something)
+    # finality: eager run, segment by segment
+    m3, _, opt3, _, _ = _setup(31)
+    s3 = TrainStep(m3, diff, opt3, bucketed=True, use_graph=False)
+    s3(inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev), t=inp["t"], noise=eps.to(dev))  # builds the plan
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    arena = s3.eng.grad_arena()
+    snaps = []
+    for j, (_, _, a0, a1) in enumerate(s3.segments):
+        s3._body(st, j)
+        torch.cuda.synchronize()
+        snaps.append((a0, a1, arena[a0:a1].clone()))
+    for a0, a1, snap in snaps:
+        assert torch.equal(arena[a0:a1], snap)
+    assert float(arena.abs().sum()) > 0

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repository root: the round's measurement artefacts into gpurun_out/<tag>_*.
+#   bash tools/collect_profiles.sh r02
+# Kernel-trace statistics and the two PMC passes are separate rocprofv3 runs (PMC passes carry --kernel-trace only).
+set -o pipefail
+TAG=${1:-rXX}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $ROOT/bench.py > $OUT/${TAG}_bench_full.json 2> $OUT/${TAG}_bench_full.err || exit 1
+echo "[collect] bench done"
+B="$ROOT/bench.py --no-cpu-baseline --train-steps 0 --no-vae --no-full-call"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bench -o b -- python3 $B > $OUT/${TAG}_prof_bench.log 2>&1 || exit 2
+echo "[collect] bench kernel stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o t -- python3 $ROOT/tools/train_prof.py > $OUT/${TAG}_prof_train.log 2>&1 || exit 3
+echo "[collect] train kernel stats done"
+P="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $P > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 4
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 $P > $OUT/${TAG}_pmc_write.log 2>&1 || exit 5
+F=$(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
+W=$(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
+python3 $ROOT/tools/pmc_traffic.py "$F" "$W" > $OUT/${TAG}_pmc_hbm_traffic.json || exit 6
+find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train -name "*kernel_stats.csv" | while read f; do cp "$f" $OUT/${TAG}_$(basename $(dirname $(dirname "$f")) | sed "s/${TAG}_prof_//")_kernel_stats.csv 2>/dev/null; done
+# the raw traces are large: keep the summaries only
+find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete
+find $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*counter_collection.csv" -delete
+echo "[collect] done"
+ls $OUT | grep "^${TAG}_"

@@ -593,7 +593,11 @@ extern "C" int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, f
     if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const XaLayer la = {gamma_a, beta_a, mq_pl_a, mot_pl_a, bias_a}, lb = {gamma_b, beta_b, mq_pl_b, mot_pl_b, bias_b};
-    if (c == 320)
+    if (c == 320) {
+        static const int nw_env = getenv("WDIFF_XATTN_NW") ? atoi(getenv("WDIFF_XATTN_NW")) : 2;
+        if (nw_env == 4 && hw % 64 == 0)
+            return launch_mfma<10, 4, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
         return launch_mfma<10, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+    }
     return launch_mfma<2, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
 }

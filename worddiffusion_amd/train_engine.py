@@ -46,8 +46,8 @@ class TrainPlan(Plan):
         self.bwd: List[tuple] = []
         self.dout: Optional[torch.Tensor] = None
 
-    def run_bwd(self, stream):
-        self._run(self.bwd, stream)
+    def run_bwd(self, stream, begin: int = 0, end: Optional[int] = None):
+        self._run(self.bwd[begin:end], stream)
 
 
 def _rup(x: int, m: int) -> int:
@@ -66,6 +66,14 @@ class TrainEngine(UNetEngine):
         self._arena_used = 0
         self.defer_bias_sums = os.environ.get("WDIFF_DEFER_BIAS", "1") != "0"
         self._deferred, self._deferred_outs = [], {}
+        # data-parallel overlap: the backward list is cut into NBUCKETS segments such that after segment j a PREFIX of the
+        # gradient arena is final (the arena is carved in the order the backward list first writes the gradients, so a prefix
+        # = the layers nearest the output) - TrainStep all-reduces that prefix while the next segment runs
+        self.nbuckets = int(os.environ.get("WDIFF_GRAD_BUCKETS", "3"))
+        self._carve_order: List[tuple] = []          # (data_ptr, arena offset, rounded numel) in carve order
+        self._done_at: Dict[int, int] = {}           # gradient buffer data_ptr -> index of the last closure that writes it
+        self._closure = 0
+        self._cut_closures: Optional[List[int]] = None  # closures after which a bucket ends (fixed by the first plan)
 
     def set_precision(self, mode: str):
         old = self.npass
@@ -139,6 +147,7 @@ class TrainEngine(UNetEngine):
         for d in shape:
             n *= int(d)
         out = self._arena[self._arena_used:self._arena_used + n].view(shape)
+        self._carve_order.append((out.data_ptr(), self._arena_used, _rup(n, 64)))
         self._arena_used += _rup(n, 64)
         assert self._arena_used <= self._arena.numel()
         return out
@@ -220,6 +229,7 @@ class TrainEngine(UNetEngine):
         k = t.data_ptr()
         acc = k in self._pw
         self._pw.add(k)
+        self._done_at[k] = self._closure  # (a buffer with several writers is final after the last one)
         return int(acc)
 
     def _gacc(self, P, act: TAct):
@@ -754,6 +764,7 @@ class TrainEngine(UNetEngine):
         self._pw = set()
         self._deferred, self._deferred_outs = [], {}
         self._gn_names = {}
+        self._done_at, self._closure = {}, 0
         dev = self.device
         mc = m.model_channels
         ted = 4 * mc
@@ -876,8 +887,30 @@ class TrainEngine(UNetEngine):
                                wb="B:out.w", wgrad=self._pgrad(m.out[2].weight).view(oc, -1), dx=[(dg, last.c, 0, 0, last.c)],
                                dx_rows=Mo, dx_hw=hwo)], bias=[self._pgrad(m.out[2].bias)], npad=32)
         self._gn_bwd(P, "out.gn", [last], m.out[0], 1e-5, True, dg)
+        # closures = units of the backward list (a layer each); bucket boundaries fall between closures, where the deferred
+        # column sums collected so far are finished, so that every gradient written up to there is final
+        # (bytes the backward pass will write: the dead heads of the reference - res.*, wrd_proj, attnc, to_kv, norm1 of the base
+        # model - never get a gradient; this only balances the buckets, correctness does not depend on it)
+        def _live(name):
+            return not (name.startswith("res.") or name.startswith("wrd_proj.") or ".attnc." in name or ".to_kv." in name or
+                        (self.variant == "base" and ".norm1." in name))
+        total = sum(_rup(p.numel(), 64) for n_, p in m.named_parameters() if _live(n_))
+        first_plan = self._cut_closures is None
+        cuts_seen: List[int] = []
+        P.bwd_cuts = []  # [(index into P.bwd where the segment ends, closure index)]
+        self._closure = 1
         for fn in reversed(self._tape):
             fn()
+            want = (first_plan and self.nbuckets > 1 and len(cuts_seen) < self.nbuckets - 1 and
+                    self._arena_used >= (len(cuts_seen) + 1) * total // self.nbuckets) or \
+                   (not first_plan and self._closure in self._cut_closures)
+            if want:
+                self._flush_deferred(P)
+                cuts_seen.append(self._closure)
+                P.bwd_cuts.append((len(P.bwd), self._closure))
+            self._closure += 1
+        if first_plan:
+            self._cut_closures = cuts_seen
         # ---- input convolution: weight / bias gradient only
         assert first.gw
         cin0 = m.in_channels
@@ -940,6 +973,21 @@ class TrainEngine(UNetEngine):
                                                 dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
         self._flush_deferred(P)
         self._tape = []
+        # arena prefix that is final at each cut: the longest prefix (in carve order) of buffers whose last writer is a closure
+        # <= the cut's (buffers never written by this plan - dead heads - count as final)
+        P.bwd_segments = []  # [(bwd_begin, bwd_end, arena_begin, arena_end)]
+        lo_op, lo_ar = 0, 0
+        for (op_end, closure) in P.bwd_cuts:
+            hi_ar = lo_ar
+            for (ptr, off, n) in self._carve_order:
+                if off < lo_ar:
+                    continue
+                if self._done_at.get(ptr, 0) > closure:
+                    break
+                hi_ar = off + n
+            P.bwd_segments.append((lo_op, op_end, lo_ar, hi_ar))
+            lo_op, lo_ar = op_end, hi_ar
+        P.bwd_segments.append((lo_op, len(P.bwd), lo_ar, self._arena_used))
         self._tplans[key] = P
         return P
 

@@ -5,8 +5,11 @@
     loss = mse(noise, predicted_noise); optimizer.zero_grad(); loss.backward()                 train.py:289-291
     optimizer.step(); ema.step_ema(ema_model, model)                                           train.py:293-294
 
-``TrainStep`` runs noise_images + forward + loss + backward as ONE hipGraph, then (data-parallel: one all-reduce of the
-flat gradient arena over RCCL) one multi-tensor AdamW+EMA launch and one weight-repack launch.  The same arithmetic is
+``TrainStep`` runs noise_images + forward + loss + backward as ONE hipGraph, then one multi-tensor AdamW+EMA launch and one
+weight-repack launch.  Data-parallel (world > 1): the backward list is cut into a few segments (``WDIFF_GRAD_BUCKETS``, default 3)
+after each of which a PREFIX of the flat gradient arena is final - the gradients of the layers nearest the output, which the
+backward pass finishes first; every segment is its own hipGraph and the all-reduce of its prefix (RCCL over xGMI) runs on a
+second stream while the next segment computes, so only the last bucket's collective is exposed.  The same arithmetic is
 reachable piecewise through the reference's own call surface (``model(...)``, ``loss.backward()``, ``FusedAdamW.step``);
 this class only removes the per-step host work.
 """
@@ -23,9 +26,12 @@ from .optim import FusedAdamW
 
 class TrainStep:
     def __init__(self, model, diffusion, optimizer: FusedAdamW, seed: int = 0, use_graph: bool = True,
-                 process_group=None):
+                 process_group=None, bucketed: Optional[bool] = None):
+        """``bucketed``: run the backward pass in segments with the gradient all-reduce of each segment's arena prefix
+        overlapped with the next segment (default: whenever world > 1; ``True`` at world 1 only cuts the graph - tests)."""
         self.model, self.diffusion, self.opt = model, diffusion, optimizer
         self.seed, self.use_graph = seed, use_graph
+        self._bucketed_arg = bucketed
         self.lib = N.lib()
         self.eng = model.train_engine
         self.step_index = 0
@@ -54,20 +60,68 @@ class TrainStep:
         self._scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
         self._P = P
         self._stream = torch.cuda.Stream(device=dev)
-        if self._graph is not None:
-            self.lib.wd_graph_destroy(self._graph)
-            self._graph = None
+        self._comm = torch.cuda.Stream(device=dev)
+        for g in ([self._graph] if self._graph is not None else []) + list(getattr(self, "_seg_graphs", []) or []):
+            if g is not None:
+                self.lib.wd_graph_destroy(g)
+        self._graph = None
+        self._seg_graphs = None
+        self.bucketed = (self.world > 1) if self._bucketed_arg is None else bool(self._bucketed_arg)
+        self.segments = list(getattr(P, "bwd_segments", [])) if self.bucketed else []
+        if len(self.segments) <= 1:
+            self.segments = []
 
-    def _body(self, st):
+    def _body(self, st, seg: Optional[int] = None):
+        """The whole step body (seg None), or segment ``seg`` of it: segment 0 = noise + forward + loss + the first part of the
+        backward list, the others = the following parts."""
         lib, P = self.lib, self._P
-        n = P.x_in[0].numel()
-        B = P.x_in.shape[0]
-        N.check(lib.wd_noise_images(self._x0.data_ptr(), self._eps.data_ptr(), P.t_in.data_ptr(), self._sa.data_ptr(),
-                                    self._sb.data_ptr(), B, n, P.x_in.data_ptr(), st), "wd_noise_images")
-        P.run_step(st)
-        N.check(lib.wd_mse_loss(P.out.data_ptr(), self._eps.data_ptr(), P.out.numel(), P.dout.data_ptr(), self._loss.data_ptr(),
-                                self._scratch.data_ptr(), 1024, st), "wd_mse_loss")
-        P.run_bwd(st)
+        if seg is None or seg == 0:
+            n = P.x_in[0].numel()
+            B = P.x_in.shape[0]
+            N.check(lib.wd_noise_images(self._x0.data_ptr(), self._eps.data_ptr(), P.t_in.data_ptr(), self._sa.data_ptr(),
+                                        self._sb.data_ptr(), B, n, P.x_in.data_ptr(), st), "wd_noise_images")
+            P.run_step(st)
+            N.check(lib.wd_mse_loss(P.out.data_ptr(), self._eps.data_ptr(), P.out.numel(), P.dout.data_ptr(),
+                                    self._loss.data_ptr(), self._scratch.data_ptr(), 1024, st), "wd_mse_loss")
+        if seg is None:
+            P.run_bwd(st)
+        else:
+            b0, b1, _, _ = self.segments[seg]
+            P.run_bwd(st, b0, b1)
+
+    def _capture(self, st, seg=None):
+        lib = self.lib
+        N.check(lib.wd_graph_begin(st), "wd_graph_begin")
+        g = C.c_void_p()
+        try:
+            self._body(st, seg)
+        finally:
+            rc = lib.wd_graph_end(st, C.byref(g))
+        N.check(rc, "wd_graph_end")
+        return g
+
+    def _run_bucketed(self, st):
+        """Backward in segments; after segment j the arena prefix [a0, a1) is final: its all-reduce goes to the comm stream
+        behind an event, the next segment runs meanwhile.  Returns after queueing everything; the compute stream waits for
+        the collectives before the optimiser."""
+        lib = self.lib
+        arena = self.eng.grad_arena()
+        if self.use_graph and self._seg_graphs is None:
+            self._seg_graphs = [self._capture(st, j) for j in range(len(self.segments))]
+        for j, (_, _, a0, a1) in enumerate(self.segments):
+            if self.use_graph:
+                N.check(lib.wd_graph_launch(self._seg_graphs[j], st), "wd_graph_launch")
+            else:
+                self._body(st, j)
+            if self.world > 1 and a1 > a0:
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                self._comm.wait_event(ev)
+                with torch.cuda.stream(self._comm):
+                    torch.distributed.all_reduce(arena[a0:a1], group=self.pg)  # RCCL over xGMI (gloo in the one-GPU tests)
+        if self.world > 1:
+            self._stream.wait_stream(self._comm)
+            arena.mul_(1.0 / self.world)
 
     def __call__(self, latents: torch.Tensor, text_features: torch.Tensor, labels: Optional[torch.Tensor],
                  t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
@@ -109,23 +163,19 @@ class TrainStep:
             else:
                 N.check(lib.wd_randn(self._eps.data_ptr(), B, self._eps[0].numel(), self.seed,
                                      (self.step_index * self.world + self.rank) * B, 2, st), "wd_randn")
-            if self.use_graph:
-                if self._graph is None:
-                    N.check(lib.wd_graph_begin(st), "wd_graph_begin")
-                    g = C.c_void_p()
-                    try:
-                        self._body(st)
-                    finally:
-                        rc = lib.wd_graph_end(st, C.byref(g))
-                    N.check(rc, "wd_graph_end")
-                    self._graph = g
-                N.check(lib.wd_graph_launch(self._graph, st), "wd_graph_launch")
+            if self.segments:
+                self._run_bucketed(st)
             else:
-                self._body(st)
-            if self.world > 1:
-                arena = self.eng.grad_arena()
-                torch.distributed.all_reduce(arena, group=self.pg)  # the single gradient all-reduce of the step (RCCL/xGMI)
-                arena.mul_(1.0 / self.world)
+                if self.use_graph:
+                    if self._graph is None:
+                        self._graph = self._capture(st)
+                    N.check(lib.wd_graph_launch(self._graph, st), "wd_graph_launch")
+                else:
+                    self._body(st)
+                if self.world > 1:
+                    arena = self.eng.grad_arena()
+                    torch.distributed.all_reduce(arena, group=self.pg)  # one all-reduce of the whole arena (WDIFF_GRAD_BUCKETS=1)
+                    arena.mul_(1.0 / self.world)
             self.eng.assign_grads()
             self.opt.step()
             self.eng.refresh_weights()
