@@ -35,4 +35,4 @@ for _ in range(100):
     run()
 e1.record()
 torch.cuda.synchronize()
-print(f"WDIFF_XATTN_NW={os.environ.get('WDIFF_XATTN_NW', '2')} hw={hw}: {e0.elapsed_time(e1) * 10:.1f} us per launch")
+print(f"wd_xattn_pair B={B} hw={hw} c={c}: {e0.elapsed_time(e1) * 10:.1f} us per launch")

@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                 }
             };
             auto mfma16g = [&](auto& fa_, auto& fb_) {
-#pragma unroll
+    #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int t = 0; t < 5; ++t) {
@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(256 * KS, 1) wd_gemm2_kernel(const wd_gemm_arg
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            };
+                };
             auto half_step = [&](int kit, auto& rd_a, auto& rd_b, auto& mm_a, auto& mm_b) {
                 if (stamp16) sb16[kit * 4 + 0] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -15,6 +15,21 @@ namespace {
 
 constexpr int XHJ = 64;  // (head, key) pairs padded to two 32-wide MFMA tiles
 
+// The split-bf16 planes of the folded matrices are stored FRAGMENT-MAJOR: the 16 bytes a lane of the consuming MFMA needs sit at
+// block * 1 KB + lane * 16 B, so a wave's operand load is one contiguous kilobyte (eight full lines) instead of 16-byte pieces of 16
+// to 64 different lines (row pitch 640 B / 128 B) - stamped before the change: the score phase of xattn_mfma_kernel spent ~10k of its
+// 14k cycles waiting for those pieces.
+//   Mq plane [64 hj][c], consumer v_mfma_f32_16x16x32_bf16 B operand: lane = 16 * (k chunk of 8) + (hj row in its tile of 16),
+//   block = (hj tile, 32-deep k step).
+__device__ __forceinline__ long xa_mq_index(int hj, int n, int c) {
+    return ((long)((hj >> 4) * (c >> 5) + (n >> 5)) << 9) + ((((n >> 3) & 3) * 16 + (hj & 15)) << 3) + (n & 7);
+}
+//   Mo^T plane [c][64 hj], consumer v_mfma_f32_32x32x16_bf16 B operand: lane = 32 * (hj half of 8) + (column n in its tile of 32),
+//   block = (n tile, 16-deep hj step).
+__device__ __forceinline__ long xa_mo_index(int n, int hj) {
+    return ((long)((n >> 5) * 4 + (hj >> 4)) << 9) + ((((hj >> 3) & 1) * 32 + (n & 31)) << 3) + (hj & 7);
+}
+
 __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v,
                                                          int ldv, int heads, int L, int d, float scale,
                                                          const float* __restrict__ wq, const float* __restrict__ wo, int c,
@@ -43,15 +58,16 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict
         mq[orow * c + n] = aq * scale;
         mo[orow * c + n] = ao;
         if (mq_pl) {
-            // operands of the MFMA kernel: Mq as [b][plane][64 rows hj][c], Mo transposed as [b][plane][c][64 columns hj]
+            // operands of the MFMA kernel: Mq [b][plane][64 hj x c], Mo transposed [b][plane][c x 64 hj], both fragment-major
             const int hj = h * L + j;
+            const long pq = (long)XHJ * c;
             uint32_t hi, lo;
             wd_split1(aq * scale, hi, lo);
-            mq_pl[(((long)b * 2 + 0) * XHJ + hj) * c + n] = (wd_bf16)hi;
-            mq_pl[(((long)b * 2 + 1) * XHJ + hj) * c + n] = (wd_bf16)lo;
+            mq_pl[((long)b * 2 + 0) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)hi;
+            mq_pl[((long)b * 2 + 1) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)lo;
             wd_split1(ao, hi, lo);
-            mot_pl[(((long)b * 2 + 0) * c + n) * XHJ + hj] = (wd_bf16)hi;
-            mot_pl[(((long)b * 2 + 1) * c + n) * XHJ + hj] = (wd_bf16)lo;
+            mot_pl[((long)b * 2 + 0) * pq + xa_mo_index(n, hj)] = (wd_bf16)hi;
+            mot_pl[((long)b * 2 + 1) * pq + xa_mo_index(n, hj)] = (wd_bf16)lo;
         }
     }
 }
@@ -309,6 +325,12 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
             if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
         }
     const int rt = wave % RTN, cg = wave / RTN;
+    constexpr int KS32 = C / 32;                 // 32-deep k-steps of the score product
+    constexpr int CH2 = KS32 >= 5 ? 5 : KS32;    // k-steps per prefetched chunk of its global operand
+    constexpr int NCH2 = KS32 / CH2;
+    static_assert(KS32 % CH2 == 0, "chunking");
+    xa_bf16x8 bh[2][CH2][2], bl[2][CH2][2];     // (outside the pass loop: the second pass's first chunk is requested in the first)
+    const int q15 = lane & 15, q4 = lane >> 4;
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
     const XaLayer& ly = ps == 0 ? la : lb;
@@ -318,18 +340,21 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     const wd_bf16* __restrict__ mot_pl = ly.mot_pl;
     const float* __restrict__ bias = ly.bias;
     const bool last = ps == NP - 1;
-    constexpr int CH = 5;  // k-steps per prefetched chunk of the global operand
-    static_assert(KSB % CH == 0 || KSB < CH, "chunking");
-    constexpr int NCH = KSB >= CH ? KSB / CH : 1, CHN = KSB >= CH ? CH : KSB;
-    xa_bf16x8 bh[2][CHN], bl[2][CHN];
-    const wd_bf16* bq = mq_pl + (((long)b * 2) * XHJ + cg * 32 + l31) * C + lh * 8;
+    // The score product runs on v_mfma_f32_16x16x32_bf16 with FOUR independent accumulators (2 token tiles x 2 (head, key) tiles of
+    // 16): as one 32 x 32 tile its 60 MFMAs are one dependent chain (stamped: 14.6k cycles for the phase, ~240 per MFMA); four
+    // chains of 30 interleave at the pipe's rate.  Operand of tile j: lane (l15 = (head, key) row, lq = 8-element k chunk).
+    const wd_bf16* bq = mq_pl + ((long)b * 2) * XHJ * C + ((long)(cg * 2) * KS32 << 9) + lane * 8;  // block (tile 2 cg + j, ks): + (j KS32 + ks) << 9
     const bool have_s = cg * 32 < HJ;
-    if (have_s) {
+    // (the first chunk of the SECOND attention's operand is requested right after the first attention's score phase, below: it
+    // lands during the softmax / output phases instead of at the top of the second pass)
+    if (have_s && ps == 0) {
 #pragma unroll
-        for (int i = 0; i < CHN; ++i) {
-            bh[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + i * 16);
-            bl[0][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + i * 16);
-        }
+        for (int i = 0; i < CH2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + ((long)(j * KS32 + i) << 9));
+                bl[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((long)(j * KS32 + i) << 9));
+            }
     }
     if (ps == 0)
         for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
@@ -369,45 +394,84 @@ __global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __rest
     }
     __syncthreads();
 
-    // ---- scores S[token][hj] = Xn . Mq^T: wave = (token tile rt, hj tile cg)
+    // ---- scores S[token][hj] = Xn . Mq^T: wave = (token tile rt of 32, hj tile cg of 32) = 2 x 2 tiles of 16 x 16
     if (have_s) {
-        xa_f32x16 acc;
+        typedef __attribute__((ext_vector_type(4))) float xa_f32x4;
+        xa_f32x4 acc[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const wd_bf16* ax = sX + (long)(rt * 32 + l31) * XP + lh * 8;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + 1 < NCH) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < CHN; ++i) {
-                    bh[(ch + 1) & 1][i] = *reinterpret_cast<const xa_bf16x8*>(bq + ((ch + 1) * CHN + i) * 16);
-                    bl[(ch + 1) & 1][i] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((ch + 1) * CHN + i) * 16);
-                }
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        const wd_bf16* ax = sX + (long)(rt * 32 + q15) * XP + q4 * 8;
+#pragma unroll
+        for (int ch = 0; ch < NCH2; ++ch) {
+            if (ch + 1 < NCH2) {
+#pragma unroll
+                for (int i = 0; i < CH2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bh[(ch + 1) & 1][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + ((long)(j * KS32 + (ch + 1) * CH2 + i) << 9));
+                        bl[(ch + 1) & 1][i][j] =
+                            *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((long)(j * KS32 + (ch + 1) * CH2 + i) << 9));
+                    }
             }
 #pragma unroll
-            for (int i = 0; i < CHN; ++i) {
-                const int ks = ch * CHN + i;
-                const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ax + ks * 16);
-                const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ax + (long)XT * XP + ks * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ch & 1][i], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ch & 1][i], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ch & 1][i], acc, 0, 0, 0);
+            for (int i = 0; i < CH2; ++i) {
+                const int ks = ch * CH2 + i;
+                xa_bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    ah[ti] = *reinterpret_cast<const xa_bf16x8*>(ax + (long)ti * 16 * XP + ks * 32);
+                    al[ti] = *reinterpret_cast<const xa_bf16x8*>(ax + (long)(XT + ti * 16) * XP + ks * 32);
+                }
+                // pass-major over the four tiles: the three products of a tile stay in their order, four MFMAs apart
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ti], bh[ch & 1][i][j], acc[ti][j], 0, 0, 0);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ti], bl[ch & 1][i][j], acc[ti][j], 0, 0, 0);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ti], bh[ch & 1][i][j], acc[ti][j], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sS[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SP + cg * 32 + l31] = acc[r];
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sS[(rt * 32 + ti * 16 + 4 * q4 + r) * SP + cg * 32 + j * 16 + q15] = acc[ti][j][r];
+        if (NP == 2 && ps == 0) {  // chunk 0 of the next attention's score operand (every product of this pass has been issued)
+            const wd_bf16* bn = lb.mq_pl + ((long)b * 2) * XHJ * C + ((long)(cg * 2) * KS32 << 9) + lane * 8;
+#pragma unroll
+            for (int i = 0; i < CH2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bn + ((long)(j * KS32 + i) << 9));
+                    bl[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bn + (long)XHJ * C + ((long)(j * KS32 + i) << 9));
+                }
+        }
     }
     // the operand of the output product does not depend on the softmax: request it now, it lands during the softmax
     constexpr int KD = 3;  // heads * L <= 40 -> three 16-deep k-steps cover the (head, key) pairs
     xa_bf16x8 mh[KD][NT], ml[KD][NT];
     {
-        const wd_bf16* bm = mot_pl + (((long)b * 2) * C + cg * NT * 32 + l31) * XHJ + lh * 8;
+        const wd_bf16* bm = mot_pl + ((long)b * 2) * C * XHJ + ((long)(cg * NT) * 4 << 9) + lane * 8;  // block (n tile, ks)
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                mh[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + (long)t * 32 * XHJ + ks * 16);
-                ml[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + ((long)C + t * 32) * XHJ + ks * 16);
+                mh[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + ((long)(t * 4 + ks) << 9));
+                ml[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + (long)C * XHJ + ((long)(t * 4 + ks) << 9));
             }
     }
     __syncthreads();
@@ -594,9 +658,7 @@ extern "C" int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, f
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const XaLayer la = {gamma_a, beta_a, mq_pl_a, mot_pl_a, bias_a}, lb = {gamma_b, beta_b, mq_pl_b, mot_pl_b, bias_b};
     if (c == 320) {
-        static const int nw_env = getenv("WDIFF_XATTN_NW") ? atoi(getenv("WDIFF_XATTN_NW")) : 2;
-        if (nw_env == 4 && hw % 64 == 0)
-            return launch_mfma<10, 4, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+        // (64 tokens per workgroup - launch_mfma<10, 4, 2> - halves the operand fetches but leaves one workgroup per CU: 41.4 vs 39.5 us)
         return launch_mfma<10, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
     }
     return launch_mfma<2, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
