@@ -238,6 +238,35 @@ def vae_leg(dev, precision, B):
                 share_of_a_sampling_call=None)
 
 
+def epoch_leg(step, dev, B, n_items=1000):
+    """BASELINE configs[2] / SURVEY section 8d config 3: ONE epoch of the train.py batch loop (train.py:253-295: loader batch ->
+    TrainStep; the 30-batch break of train.py:263-264) over a synthetic IAM-shaped set of N = 1000 cached latents
+    ([4,8,32] ~ N(0,1) * 0.18215, 339 writers, random words) read from the tensor-only container of latents.py - host batching,
+    pinned copies and the H2D included, wall-clock."""
+    import tempfile
+    import numpy as np
+    from worddiffusion_amd.latents import CachedLatentDataset, LatentCache, save_latent_cache, train_epoch
+    rs = np.random.RandomState(0)
+    letters = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxy"
+    rows = [(f"{int(rs.randint(0, 339)):03d}", f"img{i:05d}", "".join(letters[int(k)] for k in rs.randint(0, 51, size=int(rs.randint(1, 11)))))
+            for i in range(n_items)]
+    wr = {f"{i:03d}": i for i in range(339)}
+    lat = {r[1] + ".png": torch.from_numpy((rs.standard_normal((4, 8, 32)) * 0.18215).astype(np.float32)) for r in rows}
+    with tempfile.TemporaryDirectory() as td:
+        cache = LatentCache(save_latent_cache(os.path.join(td, "latents.safetensors"), lat))
+        data = CachedLatentDataset(rows, wr, cache)
+        train_epoch(step, data, B, dev, epoch=0, seed=1, max_batches=2)  # warm-up (page cache, pinned pool)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = train_epoch(step, data, B, dev, epoch=1, seed=1, max_batches=30)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(workload="one epoch of the train.py loop over %d cached latents (latents.py container -> host batches -> TrainStep), "
+                         "batch %d, 30-batch break as train.py:263" % (n_items, B),
+                batches=res["batches"], images=res["images"], seconds=dt, images_per_sec=res["images"] / dt,
+                ms_per_batch=1e3 * dt / max(res["batches"], 1), mean_loss=res["mean_loss"])
+
+
 def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
     """BASELINE configs[2]/[3]: the train.py batch loop (noise_images -> UNet -> MSE -> backward -> AdamW -> EMA) on the same
     model and latent shape as the headline, synthetic batch resident in HBM, one gradient all-reduce per step when world > 1.
@@ -289,6 +318,11 @@ def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
     except Exception as e:
         out["bf16_single_pass"] = dict(error=f"{type(e).__name__}: {e}")
     model.set_precision("bf16x3")
+    if world == 1:
+        try:
+            out["train_epoch"] = epoch_leg(step, dev, B)
+        except Exception as e:  # an extra: never costs the line
+            out["train_epoch"] = dict(error=f"{type(e).__name__}: {e}")
     if rank == 0:
         lib = N.lib()
         eager = TrainStep(model, diff, opt, seed=5, use_graph=False)

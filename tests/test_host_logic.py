@@ -268,6 +268,12 @@ def test_latent_cache_round_trip_and_dataset(tmp_path, golden_dir):
     a = [b["image_names"] for b in ds.batches(4, seed=5, epoch=0, pin=False)]
     assert a == [b["image_names"] for b in ds.batches(4, seed=5, epoch=0, pin=False)]
     assert a != [b["image_names"] for b in ds.batches(4, seed=5, epoch=1, pin=False)]
+    # preloaded form: same batches
+    ds2 = CachedLatentDataset(rows, wr, cache)
+    assert ds2.preload()
+    for b1, b2 in zip(ds.batches(4, seed=5, epoch=0, pin=False), ds2.batches(4, seed=5, epoch=0, pin=False)):
+        assert b1["image_names"] == b2["image_names"] and b1["labels"] == b2["labels"]
+        assert torch.equal(b1["latents"], b2["latents"]) and torch.equal(b1["words"], b2["words"]) and torch.equal(b1["s_id"], b2["s_id"])
     ds_u = CachedLatentDataset([("049", rows[0][1], "to be")], wr, cache, underscore=True)
     assert ds_u[0]["word"].tolist()[:5] == [46, 41, 53, 28, 31]
     short = CachedLatentDataset(rows + [("049", "missing-image", "x")], wr, cache, skip_missing=True)

@@ -116,6 +116,26 @@ class CachedLatentDataset:
         if skip_missing:
             rows = [r for r in rows if (r[1] + suffix) in cache]
         self.rows = rows
+        self._pre = None  # (latents [N,C,H,W], words [N,L], s_id [N][, phosc [N,P]]) once preloaded
+
+    def preload(self, max_bytes: int = 2 << 30) -> bool:
+        """Reads every row's latent / word ids / writer index once into dense host tensors (the reference keeps its whole
+        dictionaries in memory too); ``batches`` then gathers rows by index instead of building 64 items per batch.  Skipped
+        (returns False) when the latents would take more than ``max_bytes``."""
+        if self._pre is not None:
+            return True
+        if not self.rows:
+            return False
+        first = self[0]
+        if first["latent"].numel() * 4 * len(self.rows) > max_bytes:
+            return False
+        items = [first] + [self[i] for i in range(1, len(self.rows))]
+        pre = [torch.stack([it["latent"] for it in items]), torch.stack([it["word"] for it in items]),
+               torch.tensor([it["s_id"] for it in items], dtype=torch.int64)]
+        if self.phosc_of is not None:
+            pre.append(torch.stack([it["phosc"] for it in items]))
+        self._pre = pre
+        return True
 
     def __len__(self) -> int:
         return len(self.rows)
@@ -145,6 +165,19 @@ class CachedLatentDataset:
             idx = mine[b0:b0 + batch_size]
             if len(idx) < batch_size and drop_last:
                 break
+            if self._pre is not None:
+                sel = torch.from_numpy(np.ascontiguousarray(idx)).long()
+                out = dict(image_names=[self.rows[int(i)][1] + self.suffix for i in idx], labels=[self.rows[int(i)][2] for i in idx],
+                           latents=self._pre[0].index_select(0, sel), words=self._pre[1].index_select(0, sel),
+                           s_id=self._pre[2].index_select(0, sel))
+                if self.phosc_of is not None:
+                    out["phosc"] = self._pre[3].index_select(0, sel)
+                if pin and torch.cuda.is_available():
+                    for k in ("latents", "words", "s_id", "phosc"):
+                        if k in out:
+                            out[k] = out[k].pin_memory()
+                yield out
+                continue
             items = [self[int(i)] for i in idx]
             out = dict(image_names=[it["image_name"] for it in items], labels=[it["label"] for it in items],
                        latents=torch.stack([it["latent"] for it in items]), words=torch.stack([it["word"] for it in items]),
@@ -166,18 +199,47 @@ def train_epoch(step, dataset: CachedLatentDataset, batch_size: int, device, epo
     ``max_batches=30`` reproduces the reference's ``if i == 30: break`` (``train.py:263-264``).  The loss stays on the
     device; it is read once at the end (the reference's per-batch ``loss.item()``, ``train.py:295``, is available through
     ``on_batch``).  Returns the number of batches / images and the mean loss."""
+    import queue
+    import threading
+    if hasattr(dataset, "preload"):
+        dataset.preload()
     nb, total = 0, None
-    for i, b in enumerate(dataset.batches(batch_size, shuffle=shuffle, seed=seed, epoch=epoch, rank=rank, world=world)):
-        if max_batches is not None and i == max_batches:
+    # host batching (container reads, stacking, pinning) runs one batch ahead on a worker thread; the id range check happens
+    # there on the host tensors, so the step itself never synchronises with the device
+    q: "queue.Queue" = queue.Queue(maxsize=2)
+    eng = getattr(step, "eng", None)
+
+    def produce():
+        try:
+            for i, b in enumerate(dataset.batches(batch_size, shuffle=shuffle, seed=seed, epoch=epoch, rank=rank, world=world)):
+                if max_batches is not None and i == max_batches:
+                    break
+                if eng is not None:
+                    eng.check_ids(b["words"], b["s_id"], b.get("phosc"))
+                q.put(b)
+            q.put(None)
+        except BaseException as e:  # surfaced in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    i = 0
+    while True:
+        b = q.get()
+        if b is None:
             break
+        if isinstance(b, BaseException):
+            raise b
         lat = b["latents"].to(device, non_blocking=True)
         words = b["words"].to(device, non_blocking=True)
         s_id = b["s_id"].to(device, non_blocking=True)
         ph = b["phosc"].to(device, non_blocking=True) if "phosc" in b else None
-        loss = step(lat, words, s_id, phoscLabels=ph)
+        loss = step(lat, words, s_id, phoscLabels=ph, **({"check": False} if eng is not None else {}))
         total = loss.clone() if total is None else total + loss
         nb += 1
         if on_batch is not None:
             on_batch(i, loss)
+        i += 1
+    th.join()
     mean = float(total.item()) / nb if nb else float("nan")
     return dict(batches=nb, images=nb * batch_size, mean_loss=mean)

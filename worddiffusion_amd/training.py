@@ -125,7 +125,7 @@ class TrainStep:
 
     def __call__(self, latents: torch.Tensor, text_features: torch.Tensor, labels: Optional[torch.Tensor],
                  t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                 phoscLabels: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 phoscLabels: Optional[torch.Tensor] = None, check: bool = True) -> torch.Tensor:
         """One optimisation step on a batch of latents [B, C, H, W]; returns the loss as a device tensor [1] (the
         reference's ``loss.item()`` per step, train.py:295, is the caller's choice)."""
         if not latents.is_cuda:
@@ -138,7 +138,8 @@ class TrainStep:
             self._prepare(B, H, W, text_features.shape[1], dev, phosc_len)
             self._key = key
         lib, P = self.lib, self._P
-        self.eng.check_ids(text_features, labels, phoscLabels)  # out-of-range ids raise here instead of faulting a kernel
+        if check:  # out-of-range ids raise here instead of faulting a kernel (device tensors: one small sync; a loader that has
+            self.eng.check_ids(text_features, labels, phoscLabels)  # checked its host tensors passes check=False)
         if t is None:
             if self._tgen is None:
                 t = self.diffusion.sample_timesteps(B)  # host RNG like the reference (train.py:281)
