@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwdiff_hip.so")
+LIB_PATH = os.environ.get("WDIFF_LIB") or os.path.join(_HERE, "libwdiff_hip.so")  # (WDIFF_LIB: A/B builds of the kernels)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wdiff_hip.h")
 
 WD_OK, WD_EINVAL, WD_ELAUNCH, WD_ESTATE = 0, -1, -2, -3

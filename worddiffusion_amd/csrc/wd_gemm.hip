@@ -2089,9 +2089,9 @@ int launch_conv3(const wd_gemm_args& a, hipStream_t st) {
 
 // ======================================================================================================
 // v8: a RING kernel (32-deep stages, four LDS buffers, one raw barrier per stage, counted vmcnt) with the DMA moved to FOUR
-// DEDICATED LOADER WAVES (12 waves per workgroup, three per SIMD at <= 168 registers).  Opt-in (WDIFF_GEMM_V8=1): on the
-// 320 x 3 x 3 convolution at B = 64 it ties wd_gemm2_kernel (85 vs 84 us), on the 5-stage 1x1 layers it is ~8 % faster
-// (17.5 vs 19.0 us).  What it was built to find out (round 2): with the parts of wd_gemm2_kernel switched off
+// DEDICATED LOADER WAVES (12 waves per workgroup, three per SIMD at <= 168 registers).  Opt-in (WDIFF_GEMM_V8=1): within
+// +-5 % of wd_gemm2_kernel on every layer shape (same box: 88-90 vs 85-86 us on the 320 x 3 x 3 convolution at B = 64, 19.9-20.3 vs
+// 20.3-20.5 us on the 5-stage 1x1 layers).  What it was built to find out (round 2): with the parts of wd_gemm2_kernel switched off
 // one at a time its MFMA, fragment-read and DMA costs ADD instead of overlapping - a wave that issues buffer_load ... lds
 // cannot feed the MFMA pipe meanwhile.  Here the eight compute waves (32 x 80 blocks of 2 x 5 tiles of
 // v_mfma_f32_16x16x32_bf16, 40 accumulator registers, which pays for TWO fragment sets: the fragments of stage k+1 are read
@@ -2353,6 +2353,11 @@ __global__ void __launch_bounds__(768, 1) wd_gemm8_kernel(const wd_gemm_args a, 
         auto step = [&](bool have1, auto& ma, auto& mb, auto& ra, auto& rb) {
             __builtin_amdgcn_s_barrier();
             const char* nb = smem + rd_off;
+            // Per-step stamps of this loop (clock64, one compute wave): barrier wait ~100-250 cycles, the first ten MFMAs of the
+            // step ~700 (the two compute waves of a SIMD together: 36 cycles per MFMA), the other twenty ~500 (14 per MFMA, the
+            // pipe's rate), 1490-1620 cycles per step - whether the 14 fragment reads of the next stage are issued at once, as here,
+            // or spread over the step (which costs registers: 168 + spills instead of 159); the loaders wait ~800 cycles per step
+            // at the barrier, i.e. they are not the limit.
 #pragma unroll
             for (int pass = (NPL == 2 ? 0 : 2); pass < 3; ++pass) {
 #pragma unroll
@@ -2579,9 +2584,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
             // second K-half group runs one stage late (see the kernel); the extra drain phase only pays on long K loops
             if (use_v4) return a.npass == 3 ? launch4<3>(a, st) : launch4<1>(a, st);
             {
-                // ring kernel with dedicated loader waves (wd_gemm8_kernel): ties the default kernel on long K loops, ~8 % faster on
-                // the 5-stage 1x1 layers; no fused GroupNorm statistics (its 768-thread epilogue would need a larger statistics
-                // scratch).  WDIFF_GEMM_V8=1 takes it wherever legal, dbg 0x80000 forces it (parity tests).
+                // ring kernel with dedicated loader waves (wd_gemm8_kernel): within +-5 % of the default kernel on every shape; no
+                // fused GroupNorm statistics (its 768-thread epilogue would need a larger statistics scratch).  WDIFF_GEMM_V8=1 takes it wherever legal, dbg 0x80000 forces it (parity tests).
                 static const int v8_env = getenv("WDIFF_GEMM_V8") ? atoi(getenv("WDIFF_GEMM_V8")) : 0;
                 bool v8ok = a.ktot % 32 == 0 && a.src[0].ntaps <= 9 && !a.stat_part && a.act != WD_ACT_GEGLU &&
                             (a.nsrc == 1 || (a.src[1].gather == nullptr && a.src[1].ntaps == 1));
