@@ -39,6 +39,19 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
+def _lib_digest():
+    """(content hash of csrc/*.hip + headers + flags, is it the one the loaded libwdiff_hip.so was built from)"""
+    try:
+        from worddiffusion_amd import build as B
+        want = B.source_digest()
+        with open(os.path.join(B.CSRC, "build", "manifest.json")) as f:
+            man = json.load(f)
+        ok = all(man.get(src.replace(".hip", ".o")) == B._digest([os.path.join(B.CSRC, src)] + B.HEADERS) for src in B.SOURCES)
+        return dict(sources=want[:16], library_built_from_these_sources=bool(ok))
+    except Exception as e:
+        return dict(error=f"{type(e).__name__}: {e}")
+
+
 def build_model(dev, precision, variant="base"):
     from worddiffusion_amd import UNetModel, UNetModelPhosc
     from worddiffusion_amd.synthetic import fill_module_
@@ -570,7 +583,7 @@ def main():
                                 precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),
                                 images_per_sec_per_gpu=value / world, output_finite=finite,
-                                per_call_setup_ms=setup_ms),
+                                per_call_setup_ms=setup_ms, kernel_sources_sha256=_lib_digest()),
                     roofline=roof, cpu_baseline=cpu, full_call=full_call, kernel_classes=prof_extra, train_step=train,
                     vae_decode=vae)
         print(json.dumps(line))

@@ -4,6 +4,8 @@
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -24,22 +26,36 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _stale(target: str, deps, manifest: dict) -> bool:
+    """An object is up to date when it exists and was built from exactly these source bytes and flags (content hash kept in
+    csrc/build/manifest.json) - not merely when its mtime is newer, which says nothing after a checkout or a copy."""
+    return not os.path.exists(target) or manifest.get(os.path.basename(target)) != _digest(deps)
 
 
 def build_native(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    mpath = os.path.join(objdir, "manifest.json")
+    try:
+        with open(mpath) as f:
+            manifest = json.load(f)
+    except (OSError, ValueError):
+        manifest = {}
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s] + HEADERS, manifest):
             jobs.append((s, o))
 
     def compile_one(job):
@@ -52,13 +68,25 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
+        for s, o in jobs:
+            manifest[os.path.basename(o)] = _digest([s] + HEADERS)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    lib_key = hashlib.sha256("".join(manifest.get(os.path.basename(o), "") for o in objs).encode()).hexdigest()
+    if force or jobs or not os.path.exists(LIB) or manifest.get("libwdiff_hip.so") != lib_key:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        manifest["libwdiff_hip.so"] = lib_key
+    with open(mpath, "w") as f:
+        json.dump(manifest, f, indent=1)
     return LIB
+
+
+def source_digest() -> str:
+    """Content hash of every kernel source + header + the compiler flags: what the library in this tree was built from
+    (recorded in csrc/build/manifest.json by build_native; bench.py / smoke() can report it)."""
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 if __name__ == "__main__":
