@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests._common import SMALL, join_all, make_args  # noqa: E402
+from tests._common import FULL, SMALL, join_all, make_args  # noqa: E402
+
+CFGS = {"small": (SMALL, (32, 64), (4, 8)), "full": (FULL, (64, 256), (8, 32))}
 
 
 def _free_port():
@@ -18,39 +20,39 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _setup(seed):
+def _setup(seed, cfg="small"):
     import copy
     from worddiffusion_amd import Diffusion, UNetModel
     from worddiffusion_amd.optim import FusedAdamW
     from worddiffusion_amd.synthetic import fill_module_
     from worddiffusion_amd.training import TrainStep
     dev = "cuda:0"
-    m = UNetModel(args=make_args(device=dev), **SMALL)
+    m = UNetModel(args=make_args(device=dev), **CFGS[cfg][0])
     fill_module_(m, seed)
     m = m.to(dev).train()
     ema = copy.deepcopy(m).eval().requires_grad_(False)
     opt = FusedAdamW(m.parameters(), lr=1e-4, ema_model=ema, step_start_ema=0)
-    diff = Diffusion(noise_steps=1000, img_size=(32, 64), args=make_args(device=dev))
+    diff = Diffusion(noise_steps=1000, img_size=CFGS[cfg][1], args=make_args(device=dev))
     return m, ema, opt, diff, TrainStep
 
 
-def _batch(B):
+def _batch(B, cfg="small"):
     from worddiffusion_amd.synthetic import synthetic_inputs
-    inp = synthetic_inputs(B, seed=9, hw=(4, 8), num_classes=SMALL["num_classes"])
+    inp = synthetic_inputs(B, seed=9, hw=CFGS[cfg][2], num_classes=CFGS[cfg][0]["num_classes"])
     eps = torch.randn(inp["x"].shape, generator=torch.Generator().manual_seed(4))
     return inp, eps
 
 
-def _rank_main(rank, world, port, out_path):
+def _rank_main(rank, world, port, out_path, cfg="small"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m, ema, opt, diff, TrainStep = _setup(31)
+        m, ema, opt, diff, TrainStep = _setup(31, cfg)
         step = TrainStep(m, diff, opt)
         assert step.world == world
-        inp, eps = _batch(8)
+        inp, eps = _batch(8, cfg)
         sl = slice(rank * 4, rank * 4 + 4)
         dev = "cuda:0"
         losses = []
@@ -65,31 +67,33 @@ def _rank_main(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_rank_train_step_equals_full_batch_step(tmp_path):
+@pytest.mark.parametrize("cfg", ["small", "full"])
+def test_two_rank_train_step_equals_full_batch_step(tmp_path, cfg):
+    """cfg "full" = the 320-channel latent config of BASELINE configs[3] (145 MB gradient arena, three all-reduced prefixes)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "rank0.pt")
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out, cfg)) for r in range(2)]
     for p in procs:
         p.start()
     join_all(procs, 600)
     got = torch.load(out, weights_only=True)
     # single process, whole batch
-    m, ema, opt, diff, TrainStep = _setup(31)
+    m, ema, opt, diff, TrainStep = _setup(31, cfg)
     step = TrainStep(m, diff, opt)
-    inp, eps = _batch(8)
+    inp, eps = _batch(8, cfg)
     dev = "cuda:0"
     for _ in range(2):
         step(inp["x"].to(dev), inp["context"].to(dev), inp["y"].to(dev), t=inp["t"], noise=eps.to(dev))
     torch.cuda.synchronize()
-    init, _, _, _, _ = _setup(31)
+    init, _, _, _, _ = _setup(31, cfg)
     worst = 0.0
     for k, ref in m.state_dict().items():
         ref = ref.detach().cpu().double()
         upd = (ref - init.state_dict()[k].detach().cpu().double()).norm()
-        if ref.numel() < 256 or float(upd) == 0.0:
-            continue
+        if ref.numel() < 256 or float(upd) == 0.0 or k.endswith("linear_key.bias"):
+            continue  # (the key bias of Word_Attention has an analytically zero gradient: Adam steps on rounding noise)
         rel = float((got["params"][k].double() - ref).norm() / upd)
         worst = max(worst, rel)
         assert rel < 0.05, (k, rel)  # mean of the two half-batch gradients == full-batch gradient (up to Adam sign flips)

@@ -141,11 +141,6 @@ class CharacterEncoderParams(Holder):
         self.positional_encoding = positional_encoding_table(max_seq_len, dim)
 
 
-class ConvInParams(Holder):
-    """``TimestepEmbedSequential(conv_nd(...))`` of input_blocks[0]: key ``input_blocks.0.0.weight``."""
-    kind = "conv"
-
-
 class ResBlockConditionalParams(Holder):
     """``self.res = ResBlockConditional(32, 1280, 0.2, 320, use_conv=True, down=True)`` (unet.py:1472):
     built by the reference constructor, present in its checkpoints, never called (``if 0:`` at unet.py:1593)."""
