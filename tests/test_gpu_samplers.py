@@ -283,3 +283,31 @@ def test_data_parallel_noise_rows_differ_by_rank():
     N.check(lib.wd_randn(whole.data_ptr(), 2 * B, n, 0, 0, 2, st), "wd_randn")
     assert torch.equal(torch.cat([rows(0, 2, 0), rows(0, 2, 1)]), whole.cpu())
     assert not torch.equal(rows(0, 2, 0), rows(0, 2, 1)) and not torch.equal(rows(0, 2, 1), rows(1, 2, 0))
+
+
+def test_film_table_chunks_equal_the_per_step_path(monkeypatch):
+    """The sampler tabulates the FiLM vectors per CHUNK of timesteps (engine.FILM_CHUNK_ROWS rows resident).  With chunks of 8
+    timesteps a 40-step trajectory crosses five chunk boundaries: same result as one chunk holding every step, and as the
+    per-step path (time MLP + emb_layers evaluated inside every step), graph and eager."""
+    import worddiffusion_amd.engine as E
+    args = make_args(device=DEV)
+    labels = torch.tensor([1, 7, 3], dtype=torch.int64)
+    words = ["MOVE", "a", "Zebra"]
+
+    def run(chunk_rows, tabulate, use_graph=True):
+        monkeypatch.setattr(E, "FILM_CHUNK_ROWS", chunk_rows)
+        m = fill_module_(UNetModel(args=args, **SMALL), 5).to(DEV).eval()  # fresh engine: plans are cached per model
+        diff = Diffusion(noise_steps=40, img_size=(32, 64), args=args)
+        diff.tabulate_film = tabulate
+        out = diff.sampling(m, None, 3, words, labels, args, seed=11, use_graph=use_graph)
+        P = next(iter(m.engine._plans.values()))
+        return out, getattr(P, "film_nchunks", 0)
+
+    whole, n1 = run(1 << 20, True)
+    chunked, n5 = run(16, True)
+    assert n1 == 1 and n5 == 5
+    assert torch.equal(whole, chunked)
+    eager, _ = run(16, True, use_graph=False)
+    assert torch.equal(chunked, eager)
+    per_step, n0 = run(16, False)
+    assert n0 == 0 and max_rel(per_step.cpu(), whole.cpu()) < 1e-5
