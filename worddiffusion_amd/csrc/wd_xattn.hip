@@ -10,6 +10,7 @@
 // Everything is fp32 (VALU): LayerNorm, 2 x (64 tokens x 320 x 40) products per workgroup out of LDS, softmax, residual.
 #include "wd_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -30,11 +31,26 @@ __device__ __forceinline__ long xa_mo_index(int n, int hj) {
     return ((long)((n >> 5) * 4 + (hj >> 4)) << 9) + ((((hj >> 3) & 1) * 32 + (n & 31)) << 3) + (hj & 7);
 }
 
+//   16-token kernel (xattn16_kernel): Mo^T per tile of 16 columns = one kilobyte for the hj 0..31 step of v_mfma_f32_16x16x32_bf16
+//   (lane = 16 * (hj chunk of 8) + column) followed by half a kilobyte for the hj 32..47 step of v_mfma_f32_16x16x16_bf16
+//   (lane = 16 * (hj chunk of 4) + column); heads * L <= 40 < 48.
+__device__ __forceinline__ long xa_mo16_index(int n, int hj) {
+    const long t = (long)(n >> 4) * 768;
+    if (hj < 32) return t + ((((hj >> 3) & 3) * 16 + (n & 15)) << 3) + (hj & 7);
+    return t + 512 + (((((hj - 32) >> 2) & 3) * 16 + (n & 15)) << 2) + (hj & 3);
+}
+
+// which MFMA kernel consumes the planes (the fold writes Mo^T in its layout): 16 tokens per workgroup unless WDIFF_XATTN32=1
+bool xa_tokens16() {
+    static const bool v = !getenv("WDIFF_XATTN32");
+    return v;
+}
+
 __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v,
                                                          int ldv, int heads, int L, int d, float scale,
                                                          const float* __restrict__ wq, const float* __restrict__ wo, int c,
                                                          float* __restrict__ mq, float* __restrict__ mo,
-                                                         wd_bf16* __restrict__ mq_pl, wd_bf16* __restrict__ mot_pl) {
+                                                         wd_bf16* __restrict__ mq_pl, wd_bf16* __restrict__ mot_pl, int mo16) {
     // grid (L, heads, batch); one (b, h, j) row of both matrices per workgroup
     extern __shared__ float s_kv[];  // [2][d]
     const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -66,8 +82,9 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict
             mq_pl[((long)b * 2 + 0) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)hi;
             mq_pl[((long)b * 2 + 1) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)lo;
             wd_split1(ao, hi, lo);
-            mot_pl[((long)b * 2 + 0) * pq + xa_mo_index(n, hj)] = (wd_bf16)hi;
-            mot_pl[((long)b * 2 + 1) * pq + xa_mo_index(n, hj)] = (wd_bf16)lo;
+            const long io = mo16 ? xa_mo16_index(n, hj) : xa_mo_index(n, hj);
+            mot_pl[((long)b * 2 + 0) * pq + io] = (wd_bf16)hi;
+            mot_pl[((long)b * 2 + 1) * pq + io] = (wd_bf16)lo;
         }
     }
 }
@@ -590,6 +607,315 @@ int launch_mfma(const float* x, int ld, int batch, int hw, const XaLayer& la, co
     return wd_check_launch();
 }
 
+// ---- 16 tokens per workgroup of two waves: twice the workgroups of xattn_mfma_kernel (B = 64 at 8 x 32: 1024, four per CU = two
+// waves per SIMD) with half the dependent chain each.  The 32-token kernel runs one wave per SIMD, so every memory and LDS latency of
+// its chain (rows -> LayerNorm -> scores -> softmax -> output -> epilogue, twice) is exposed: 128 workgroups took 30 us, 512 took 40.
+//   scores: v_mfma_f32_16x16x32_bf16, the (head, key) tiles of 16 dealt to the waves (wave 0: tiles 0 and 1, wave 1: tile 2);
+//   output: per wave C / 32 column tiles of 16: one 16x16x32 step over hj 0..31 and one 16x16x16 step over hj 32..47.
+typedef __attribute__((ext_vector_type(4))) float xa_f32x4;
+typedef __attribute__((ext_vector_type(4))) short xa_s16x4;
+
+template <int NI, int NP, int LL>  // c = NI * 32; NP attentions chained; LL = keys per head when known at compile time (0: run time)
+__global__ void __launch_bounds__(128, 2) xattn16_kernel(const float* __restrict__ x, int ld, int hw, const XaLayer la,
+                                                         const XaLayer lb, float eps, int heads, int L,
+                                                         float* __restrict__ out, int out_ld,
+                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                         float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
+                                                         int n_ld) {
+    constexpr int XT = 16, NTH = 128;
+    constexpr int C = NI * 32, XP = C + 8, OP = C + 4, SP = 49, PP = 56;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wd_bf16* sX = reinterpret_cast<wd_bf16*>(smem);                              // [2][XT][XP] normalised tokens (planes)
+    float* sO = reinterpret_cast<float*>(smem);                                   // [XT][OP] output image (overlays sX)
+    constexpr size_t XBYTES = (size_t)2 * XT * XP * 2 > (size_t)XT * OP * 4 ? (size_t)2 * XT * XP * 2 : (size_t)XT * OP * 4;
+    float* sS = reinterpret_cast<float*>(smem + XBYTES);                          // [XT][SP] scores
+    wd_bf16* sP = reinterpret_cast<wd_bf16*>(smem + XBYTES + (size_t)XT * SP * 4);  // [2][XT][PP] probabilities (planes)
+    const int b = blockIdx.x, t0 = blockIdx.y * XT;  // consecutive workgroup ids = consecutive samples (see xattn_mfma_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HJ = heads * L;
+    const long row0 = (long)b * hw + t0;
+    const int ntok = min(XT, hw - t0);
+    constexpr int FI = NI / 2;  // float4 per lane per row; a row is handled by a quarter wave, eight rows per wave
+    const int qd = lane >> 4, l15 = lane & 15;
+    float4 xr[2][FI];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int t = wave * 8 + k * 4 + qd;
+            xr[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
+        }
+    constexpr int KS32 = C / 32;
+    constexpr int CH2 = KS32 >= 5 ? 5 : KS32;
+    constexpr int NCH2 = KS32 / CH2;
+    static_assert(KS32 % CH2 == 0, "chunking");
+    // (head, key) tiles of this wave: two for wave 0, the rest (at most one: heads * L <= 40) for wave 1
+    const int ntile = (HJ + 15) >> 4;
+    const int tile0 = wave * 2;
+    const int nj = min(2, max(0, ntile - tile0));
+    xa_bf16x8 bh[2][CH2][2], bl[2][CH2][2];
+    const long pq = (long)XHJ * C;
+    const long bq_off = ((long)b * 2) * pq + ((long)tile0 * KS32 << 9) + lane * 8;  // block (tile0 + j, ks): + (j KS32 + ks) << 9
+    auto request = [&](const wd_bf16* base, auto bufc, int ch) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int i = 0; i < CH2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // (unconditional: a predicated load keeps the register's previous value alive across the whole pass; a tile this
+                // wave does not own re-reads tile0's lines, which its L1 holds)
+                const int jj = j < nj ? j : 0;
+                bh[BUF][i][j] = *reinterpret_cast<const xa_bf16x8*>(base + ((long)(jj * KS32 + ch * CH2 + i) << 9));
+                bl[BUF][i][j] = *reinterpret_cast<const xa_bf16x8*>(base + pq + ((long)(jj * KS32 + ch * CH2 + i) << 9));
+            }
+    };
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
+    request(la.mq_pl + bq_off, B0(), 0);
+    for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+    const XaLayer& ly = ps == 0 ? la : lb;
+    const float* __restrict__ gamma = ly.gamma;
+    const float* __restrict__ beta = ly.beta;
+    const float* __restrict__ bias = ly.bias;
+    const bool last = ps == NP - 1;
+    const wd_bf16* bq = ly.mq_pl + bq_off;
+    // ---- LayerNorm -> split planes in LDS
+    {
+        float4 ga[FI], be[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            ga[i] = *reinterpret_cast<const float4*>(gamma + (l15 + 16 * i) * 4);
+            be[i] = *reinterpret_cast<const float4*>(beta + (l15 + 16 * i) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = wave * 8 + k * 4 + qd;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
+            const float mean = wd_row16_sum(s) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps);
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                float4 o;
+                o.x = (xr[k][i].x - mean) * rstd * ga[i].x + be[i].x; o.y = (xr[k][i].y - mean) * rstd * ga[i].y + be[i].y;
+                o.z = (xr[k][i].z - mean) * rstd * ga[i].z + be[i].z; o.w = (xr[k][i].w - mean) * rstd * ga[i].w + be[i].w;
+                uint2 hi, lo;
+                wd_split4(o, hi, lo);
+                *reinterpret_cast<uint2*>(sX + (long)t * XP + (l15 + 16 * i) * 4) = hi;
+                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + (l15 + 16 * i) * 4) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- scores S[token][hj] = Xn . Mq^T: operand lane (l15 = row of the tile, qd = 8-element k chunk)
+    if (nj > 0) {
+        xa_f32x4 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+        const wd_bf16* ax = sX + (long)l15 * XP + qd * 8;
+#pragma unroll
+        for (int ch = 0; ch < NCH2; ++ch) {
+            if (ch + 1 < NCH2) {
+                if ((ch + 1) & 1) request(bq, B1(), ch + 1); else request(bq, B0(), ch + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < CH2; ++i) {
+                const int ks = ch * CH2 + i;
+                const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ax + ks * 32);
+                const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ax + (long)XT * XP + ks * 32);
+                if (nj == 2) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][1], acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][0], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][0], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][0], acc[0], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < nj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sS[(4 * qd + r) * SP + (tile0 + j) * 16 + l15] = acc[j][r];
+            }
+    }
+    // the operand of the output product does not depend on the softmax: request it now, it lands during the softmax
+    xa_bf16x8 mh0[NI], ml0[NI];
+    xa_s16x4 mh1[NI], ml1[NI];
+    {
+        const wd_bf16* bm = ly.mot_pl + ((long)b * 2) * pq + (long)(wave * NI) * 768;
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            mh0[t] = *reinterpret_cast<const xa_bf16x8*>(bm + t * 768 + lane * 8);
+            ml0[t] = *reinterpret_cast<const xa_bf16x8*>(bm + pq + t * 768 + lane * 8);
+            mh1[t] = *reinterpret_cast<const xa_s16x4*>(bm + t * 768 + 512 + lane * 4);
+            ml1[t] = *reinterpret_cast<const xa_s16x4*>(bm + pq + t * 768 + 512 + lane * 4);
+        }
+    }
+    __syncthreads();
+    // ---- softmax per (token, head) -> probability planes
+    for (int idx = tid; idx < XT * heads; idx += NTH) {
+        const int t = idx / heads, h = idx - t * heads;
+        const float* pr = sS + t * SP + h * L;
+        wd_bf16* ph = sP + (long)t * PP + h * L;
+        if (LL > 0) {
+            constexpr int LN_ = LL > 0 ? LL : 1;
+            float v[LN_];
+#pragma unroll
+            for (int j = 0; j < LN_; ++j) v[j] = pr[j];
+            float mx = v[0];
+#pragma unroll
+            for (int j = 1; j < LN_; ++j) mx = fmaxf(mx, v[j]);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < LN_; ++j) {
+                v[j] = __expf(v[j] - mx);
+                sum += v[j];
+            }
+            const float inv = __fdividef(1.f, sum);
+#pragma unroll
+            for (int j = 0; j < LN_; ++j) {
+                uint32_t hi, lo;
+                wd_split1(v[j] * inv, hi, lo);
+                ph[j] = (wd_bf16)hi;
+                ph[(long)XT * PP + j] = (wd_bf16)lo;
+            }
+        } else {
+            float mx = -3.4e38f;
+            for (int j = 0; j < L; ++j) mx = fmaxf(mx, pr[j]);
+            float sum = 0.f;
+            for (int j = 0; j < L; ++j) sum += __expf(pr[j] - mx);
+            const float inv = __fdividef(1.f, sum);
+            for (int j = 0; j < L; ++j) {
+                uint32_t hi, lo;
+                wd_split1(__expf(pr[j] - mx) * inv, hi, lo);
+                ph[j] = (wd_bf16)hi;
+                ph[(long)XT * PP + j] = (wd_bf16)lo;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- output image O[token][n] = P . Mo: NI column tiles of 16 per wave, independent accumulators
+    {
+        xa_f32x4 o[NI];
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][r] = 0.f;
+        const wd_bf16* ap = sP + (long)l15 * PP;
+        const xa_bf16x8 ah0 = *reinterpret_cast<const xa_bf16x8*>(ap + qd * 8);
+        const xa_bf16x8 al0 = *reinterpret_cast<const xa_bf16x8*>(ap + (long)XT * PP + qd * 8);
+        const xa_s16x4 ah1 = *reinterpret_cast<const xa_s16x4*>(ap + 32 + qd * 4);
+        const xa_s16x4 al1 = *reinterpret_cast<const xa_s16x4*>(ap + (long)XT * PP + 32 + qd * 4);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, mh0[t], o[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al1, mh1[t], o[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, ml0[t], o[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah1, ml1[t], o[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, mh0[t], o[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah1, mh1[t], o[t], 0, 0, 0);
+        // (sX is dead: both waves passed the barrier after the score phase)
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sO[(4 * qd + r) * OP + (wave * NI + t) * 16 + l15] = o[t][r];
+    }
+    // chunk 0 of the next attention's score operand: lands during the epilogue and the next LayerNorm
+    __builtin_amdgcn_sched_barrier(0);  // (hoisted above the output product these 80 registers would spill)
+    if (NP == 2 && ps == 0) request(lb.mq_pl + bq_off, B0(), 0);
+    __syncthreads();
+    // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
+    {
+        float4 bi[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) bi[i] = *reinterpret_cast<const float4*>(bias + (l15 + 16 * i) * 4);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = wave * 8 + k * 4 + qd;
+            const bool ok = t < ntok;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int n = (l15 + 16 * i) * 4;
+                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + n);
+                xr[k][i] = make_float4(at.x + bi[i].x + xr[k][i].x, at.y + bi[i].y + xr[k][i].y, at.z + bi[i].z + xr[k][i].z,
+                                       at.w + bi[i].w + xr[k][i].w);
+                if (ok && last) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
+                s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
+            }
+            if (n_hi && last) {
+                const float mean = wd_row16_sum(s) / (float)C;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+                const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps2);
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < FI; ++i) {
+                        const int n = (l15 + 16 * i) * 4;
+                        const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + n);
+                        const float4 b2 = *reinterpret_cast<const float4*>(beta2 + n);
+                        float4 y;
+                        y.x = (xr[k][i].x - mean) * rstd * g2.x + b2.x; y.y = (xr[k][i].y - mean) * rstd * g2.y + b2.y;
+                        y.z = (xr[k][i].z - mean) * rstd * g2.z + b2.z; y.w = (xr[k][i].w - mean) * rstd * g2.w + b2.w;
+                        uint2 hi, lo;
+                        wd_split4(y, hi, lo);
+                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + n) = hi;
+                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + n) = lo;
+                    }
+                }
+            }
+        }
+    }
+    if (!last) __syncthreads();  // the output image is consumed before the next attention overwrites the token planes
+    }
+}
+
+template <int NI, int NP>
+int launch16(const float* x, int ld, int batch, int hw, const XaLayer& la, const XaLayer& lb, float eps, int heads, int L,
+             float* out, int out_ld, const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo, int n_ld,
+             hipStream_t st) {
+    constexpr int C = NI * 32, XTM = 16;
+    constexpr size_t xb = (size_t)2 * XTM * (C + 8) * 2 > (size_t)XTM * (C + 4) * 4 ? (size_t)2 * XTM * (C + 8) * 2 : (size_t)XTM * (C + 4) * 4;
+    constexpr size_t smem = xb + (size_t)XTM * 49 * 4 + (size_t)2 * XTM * 56 * 2;
+    static_assert(smem <= 48 * 1024, "static LDS limit");
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+    const dim3 grid(batch, (hw + XTM - 1) / XTM);
+    if (L == 10)
+        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 10>), grid, dim3(128), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
+                           gamma2, beta2, eps2, n_hi, n_lo, n_ld);
+    else
+        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 0>), grid, dim3(128), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
+                           gamma2, beta2, eps2, n_hi, n_lo, n_ld);
+    return wd_check_launch();
+}
+
 }  // namespace
 
 extern "C" int wd_xattn_supported(int c, int heads, int L) {
@@ -604,7 +930,7 @@ extern "C" int wd_xattn_fold(const float* k, int ldk, const float* v, int ldv, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(xattn_fold_kernel, dim3(L, heads, batch), dim3(256), 2 * d * sizeof(float), st, k, ldk, v, ldv, heads, L, d,
-                       scale, wq, wo, c, mq, mo, mq_pl, mot_pl);
+                       scale, wq, wo, c, mq, mo, mq_pl, mot_pl, xa_tokens16() ? 1 : 0);
     return wd_check_launch();
 }
 
@@ -617,6 +943,11 @@ extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mq_pl && mot_pl && !getenv("WDIFF_XATTN_VALU")) {
         const XaLayer la = {gamma, beta, mq_pl, mot_pl, bias};
+        if (xa_tokens16()) {
+            if (c == 320)
+                return launch16<10, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+            return launch16<2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+        }
         if (c == 320)
             return launch_mfma<10, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
         return launch_mfma<2, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
@@ -657,6 +988,11 @@ extern "C" int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, f
     if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const XaLayer la = {gamma_a, beta_a, mq_pl_a, mot_pl_a, bias_a}, lb = {gamma_b, beta_b, mq_pl_b, mot_pl_b, bias_b};
+    if (xa_tokens16()) {
+        if (c == 320)
+            return launch16<10, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+        return launch16<2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+    }
     if (c == 320) {
         // (64 tokens per workgroup - launch_mfma<10, 4, 2> - halves the operand fetches but leaves one workgroup per CU: 41.4 vs 39.5 us)
         return launch_mfma<10, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
