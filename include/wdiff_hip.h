@@ -163,8 +163,10 @@ int wd_timestep_embedding(const int64_t* t, int batch, const float* freqs, int h
  *                                   Mo[b][h*L+j][n] = sum_c V[b*L+j][h*d+c] * Wo[n][h*d+c]   (fp32; wq [heads*d][c], wo [c][heads*d]).
  * wd_xattn_fused (per step): out = x + bias + softmax_heads(LN(x; gamma, beta, eps) . Mq[b]^T) . Mo[b]; when n_hi != NULL also
  * the following LayerNorm (gamma2, beta2, eps2) of `out` as split-bf16 planes.  Shapes: wd_xattn_supported(c, heads, L).
- * mq_pl [batch][2][64][c] / mot_pl [batch][2][c][64] (zero-initialised by the caller, filled by wd_xattn_fold) are the same
- * matrices as split-bf16 MFMA operands; when given, the two products of wd_xattn_fused run on MFMA (fp32 VALU otherwise). */
+ * mq_pl / mot_pl (2 * 64 * c bf16 per sample each, zero-initialised by the caller, filled by wd_xattn_fold) are the same
+ * matrices as split-bf16 MFMA operands, hi plane then lo plane, stored in the order the consuming MFMA reads them (opaque to
+ * the caller: only wd_xattn_fold writes them); when given, the two products of wd_xattn_fused run on MFMA (fp32 VALU
+ * otherwise). */
 int wd_xattn_supported(int c, int heads, int L);
 int wd_xattn_fold(const float* k, int ldk, const float* v, int ldv, int batch, int heads, int L, int d, float scale,
                   const float* wq, const float* wo, int c, float* mq, float* mo, wd_bf16* mq_pl, wd_bf16* mot_pl, void* stream);

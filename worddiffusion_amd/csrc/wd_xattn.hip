@@ -18,39 +18,24 @@ constexpr int XHJ = 64;  // (head, key) pairs padded to two 32-wide MFMA tiles
 
 // The split-bf16 planes of the folded matrices are stored FRAGMENT-MAJOR: the 16 bytes a lane of the consuming MFMA needs sit at
 // block * 1 KB + lane * 16 B, so a wave's operand load is one contiguous kilobyte (eight full lines) instead of 16-byte pieces of 16
-// to 64 different lines (row pitch 640 B / 128 B) - stamped before the change: the score phase of xattn_mfma_kernel spent ~10k of its
-// 14k cycles waiting for those pieces.
+// to 64 different lines (row pitch 640 B / 128 B) - stamped before the change: the score phase spent ~10k of its 14k cycles waiting
+// for those pieces.
 //   Mq plane [64 hj][c], consumer v_mfma_f32_16x16x32_bf16 B operand: lane = 16 * (k chunk of 8) + (hj row in its tile of 16),
 //   block = (hj tile, 32-deep k step).
 __device__ __forceinline__ long xa_mq_index(int hj, int n, int c) {
     return ((long)((hj >> 4) * (c >> 5) + (n >> 5)) << 9) + ((((n >> 3) & 3) * 16 + (hj & 15)) << 3) + (n & 7);
 }
-//   Mo^T plane [c][64 hj], consumer v_mfma_f32_32x32x16_bf16 B operand: lane = 32 * (hj half of 8) + (column n in its tile of 32),
-//   block = (n tile, 16-deep hj step).
-__device__ __forceinline__ long xa_mo_index(int n, int hj) {
-    return ((long)((n >> 5) * 4 + (hj >> 4)) << 9) + ((((hj >> 3) & 1) * 32 + (n & 31)) << 3) + (hj & 7);
-}
-
-//   16-token kernel (xattn16_kernel): Mo^T per tile of 16 columns = one kilobyte for the hj 0..31 step of v_mfma_f32_16x16x32_bf16
-//   (lane = 16 * (hj chunk of 8) + column) followed by half a kilobyte for the hj 32..47 step of v_mfma_f32_16x16x16_bf16
-//   (lane = 16 * (hj chunk of 4) + column); heads * L <= 40 < 48.
+//   Mo^T plane [c][64 hj], consumer v_mfma_f32_16x16x32_bf16 B operand: block = (column tile of 16, k-step of 32 (head, key)
+//   pairs), lane = 16 * (chunk of 8 pairs) + column.
 __device__ __forceinline__ long xa_mo16_index(int n, int hj) {
-    const long t = (long)(n >> 4) * 768;
-    if (hj < 32) return t + ((((hj >> 3) & 3) * 16 + (n & 15)) << 3) + (hj & 7);
-    return t + 512 + (((((hj - 32) >> 2) & 3) * 16 + (n & 15)) << 2) + (hj & 3);
-}
-
-// which MFMA kernel consumes the planes (the fold writes Mo^T in its layout): 16 tokens per workgroup unless WDIFF_XATTN32=1
-bool xa_tokens16() {
-    static const bool v = !getenv("WDIFF_XATTN32");
-    return v;
+    return ((long)((n >> 4) * 2 + (hj >> 5)) << 9) + ((((hj >> 3) & 3) * 16 + (n & 15)) << 3) + (hj & 7);
 }
 
 __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v,
                                                          int ldv, int heads, int L, int d, float scale,
                                                          const float* __restrict__ wq, const float* __restrict__ wo, int c,
                                                          float* __restrict__ mq, float* __restrict__ mo,
-                                                         wd_bf16* __restrict__ mq_pl, wd_bf16* __restrict__ mot_pl, int mo16) {
+                                                         wd_bf16* __restrict__ mq_pl, wd_bf16* __restrict__ mot_pl) {
     // grid (L, heads, batch); one (b, h, j) row of both matrices per workgroup
     extern __shared__ float s_kv[];  // [2][d]
     const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -82,7 +67,7 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const float* __restrict
             mq_pl[((long)b * 2 + 0) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)hi;
             mq_pl[((long)b * 2 + 1) * pq + xa_mq_index(hj, n, c)] = (wd_bf16)lo;
             wd_split1(ao, hi, lo);
-            const long io = mo16 ? xa_mo16_index(n, hj) : xa_mo_index(n, hj);
+            const long io = xa_mo16_index(n, hj);
             mot_pl[((long)b * 2 + 0) * pq + io] = (wd_bf16)hi;
             mot_pl[((long)b * 2 + 1) * pq + io] = (wd_bf16)lo;
         }
@@ -288,10 +273,9 @@ int launch_fused(const float* x, int ld, int batch, int hw, const float* gamma, 
 }
 
 
-// ---- MFMA form of the fused kernel: the two products run on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (the
-// normalised tokens and the probabilities from LDS, the folded matrices straight from L2), everything else as above.
+// ---- MFMA form of the fused kernel (split-bf16 operands: the normalised tokens and the probabilities from LDS, the folded
+// matrices straight from L2), everything else as above.
 typedef __attribute__((ext_vector_type(8))) __bf16 xa_bf16x8;
-typedef __attribute__((ext_vector_type(16))) float xa_f32x16;
 
 struct XaLayer {  // one folded cross-attention: its LayerNorm, the folded matrices of this batch, the to_out bias
     const float* gamma;
@@ -301,473 +285,150 @@ struct XaLayer {  // one folded cross-attention: its LayerNorm, the folded matri
     const float* bias;
 };
 
-// NP = 2 chains the two cross-attentions of a base-model transformer block (both token-local): the intermediate token
-// stream never leaves the registers.
-template <int NI, int NW, int NP>  // c = NI * 32 (NI even); NW waves = 16 * NW tokens per workgroup
-__global__ void __launch_bounds__(64 * NW) xattn_mfma_kernel(const float* __restrict__ x, int ld, int hw, const XaLayer la,
-                                                         const XaLayer lb, float eps, int heads, int L,
-                                                         float* __restrict__ out, int out_ld,
-                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
-                                                         float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
-                                                         int n_ld) {
-    constexpr int XT = 16 * NW, NTH = 64 * NW, RTN = NW / 2;  // token tiles of 32: RTN; the other wave index picks columns
-    constexpr int C = NI * 32, C4 = C / 4, XP = C + 8, OP = C + 4, SP = XHJ + 1, PP = XHJ + 8, NT = NI / 2, KSB = C / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    wd_bf16* sX = reinterpret_cast<wd_bf16*>(smem);                              // [2][XT][XP] normalised tokens (planes)
-    float* sO = reinterpret_cast<float*>(smem);                                   // [XT][OP] output image (overlays sX)
-    constexpr size_t XBYTES = (size_t)2 * XT * XP * 2 > (size_t)XT * OP * 4 ? (size_t)2 * XT * XP * 2 : (size_t)XT * OP * 4;
-    float* sS = reinterpret_cast<float*>(smem + XBYTES);                          // [XT][SP] scores
-    wd_bf16* sP = reinterpret_cast<wd_bf16*>(smem + XBYTES + (size_t)XT * SP * 4);  // [2][XT][PP] probabilities (planes)
-    // grid (batch, token tiles): consecutive workgroup ids = consecutive samples, so the token tiles of one sample (which
-    // share its folded matrices) are dealt to the same XCD and find them in its L2
-    const int b = blockIdx.x, t0 = blockIdx.y * XT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int HJ = heads * L;
-    const long row0 = (long)b * hw + t0;
-    const int ntok = min(XT, hw - t0);
-
-    // ---- all 16 token rows of this wave and the first chunk of the score operand are requested up front (one exposed
-    // memory latency); the raw rows stay in registers for the residual add of the epilogue.  A row is handled by a
-    // quarter wave (16 lanes x FI float4 each): four rows in flight per wave, reductions stay inside a DPP row.
-    constexpr int FI = NI / 2;  // float4 per lane per row: c / 4 / 16
-    const int qd = lane >> 4, l15 = lane & 15;
-    float4 xr[4][FI];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const int t = wave * 16 + k * 4 + qd;
-            xr[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
-        }
-    const int rt = wave % RTN, cg = wave / RTN;
-    constexpr int KS32 = C / 32;                 // 32-deep k-steps of the score product
-    constexpr int CH2 = KS32 >= 5 ? 5 : KS32;    // k-steps per prefetched chunk of its global operand
-    constexpr int NCH2 = KS32 / CH2;
-    static_assert(KS32 % CH2 == 0, "chunking");
-    xa_bf16x8 bh[2][CH2][2], bl[2][CH2][2];     // (outside the pass loop: the second pass's first chunk is requested in the first)
-    const int q15 = lane & 15, q4 = lane >> 4;
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-    const XaLayer& ly = ps == 0 ? la : lb;
-    const float* __restrict__ gamma = ly.gamma;
-    const float* __restrict__ beta = ly.beta;
-    const wd_bf16* __restrict__ mq_pl = ly.mq_pl;
-    const wd_bf16* __restrict__ mot_pl = ly.mot_pl;
-    const float* __restrict__ bias = ly.bias;
-    const bool last = ps == NP - 1;
-    // The score product runs on v_mfma_f32_16x16x32_bf16 with FOUR independent accumulators (2 token tiles x 2 (head, key) tiles of
-    // 16): as one 32 x 32 tile its 60 MFMAs are one dependent chain (stamped: 14.6k cycles for the phase, ~240 per MFMA); four
-    // chains of 30 interleave at the pipe's rate.  Operand of tile j: lane (l15 = (head, key) row, lq = 8-element k chunk).
-    const wd_bf16* bq = mq_pl + ((long)b * 2) * XHJ * C + ((long)(cg * 2) * KS32 << 9) + lane * 8;  // block (tile 2 cg + j, ks): + (j KS32 + ks) << 9
-    const bool have_s = cg * 32 < HJ;
-    // (the first chunk of the SECOND attention's operand is requested right after the first attention's score phase, below: it
-    // lands during the softmax / output phases instead of at the top of the second pass)
-    if (have_s && ps == 0) {
-#pragma unroll
-        for (int i = 0; i < CH2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + ((long)(j * KS32 + i) << 9));
-                bl[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((long)(j * KS32 + i) << 9));
-            }
-    }
-    if (ps == 0)
-        for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
-    // ---- LayerNorm -> split planes in LDS
-    {
-        float4 ga[FI], be[FI];
-#pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            ga[i] = *reinterpret_cast<const float4*>(gamma + (l15 + 16 * i) * 4);
-            be[i] = *reinterpret_cast<const float4*>(beta + (l15 + 16 * i) * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = wave * 16 + k * 4 + qd;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
-            const float mean = wd_row16_sum(s) / (float)C;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps);
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                float4 o;
-                o.x = (xr[k][i].x - mean) * rstd * ga[i].x + be[i].x; o.y = (xr[k][i].y - mean) * rstd * ga[i].y + be[i].y;
-                o.z = (xr[k][i].z - mean) * rstd * ga[i].z + be[i].z; o.w = (xr[k][i].w - mean) * rstd * ga[i].w + be[i].w;
-                uint2 hi, lo;
-                wd_split4(o, hi, lo);
-                *reinterpret_cast<uint2*>(sX + (long)t * XP + (l15 + 16 * i) * 4) = hi;
-                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + (l15 + 16 * i) * 4) = lo;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- scores S[token][hj] = Xn . Mq^T: wave = (token tile rt of 32, hj tile cg of 32) = 2 x 2 tiles of 16 x 16
-    if (have_s) {
-        typedef __attribute__((ext_vector_type(4))) float xa_f32x4;
-        xa_f32x4 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        const wd_bf16* ax = sX + (long)(rt * 32 + q15) * XP + q4 * 8;
-#pragma unroll
-        for (int ch = 0; ch < NCH2; ++ch) {
-            if (ch + 1 < NCH2) {
-#pragma unroll
-                for (int i = 0; i < CH2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        bh[(ch + 1) & 1][i][j] = *reinterpret_cast<const xa_bf16x8*>(bq + ((long)(j * KS32 + (ch + 1) * CH2 + i) << 9));
-                        bl[(ch + 1) & 1][i][j] =
-                            *reinterpret_cast<const xa_bf16x8*>(bq + (long)XHJ * C + ((long)(j * KS32 + (ch + 1) * CH2 + i) << 9));
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < CH2; ++i) {
-                const int ks = ch * CH2 + i;
-                xa_bf16x8 ah[2], al[2];
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    ah[ti] = *reinterpret_cast<const xa_bf16x8*>(ax + (long)ti * 16 * XP + ks * 32);
-                    al[ti] = *reinterpret_cast<const xa_bf16x8*>(ax + (long)(XT + ti * 16) * XP + ks * 32);
-                }
-                // pass-major over the four tiles: the three products of a tile stay in their order, four MFMAs apart
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ti], bh[ch & 1][i][j], acc[ti][j], 0, 0, 0);
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ti], bl[ch & 1][i][j], acc[ti][j], 0, 0, 0);
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ti], bh[ch & 1][i][j], acc[ti][j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sS[(rt * 32 + ti * 16 + 4 * q4 + r) * SP + cg * 32 + j * 16 + q15] = acc[ti][j][r];
-        if (NP == 2 && ps == 0) {  // chunk 0 of the next attention's score operand (every product of this pass has been issued)
-            const wd_bf16* bn = lb.mq_pl + ((long)b * 2) * XHJ * C + ((long)(cg * 2) * KS32 << 9) + lane * 8;
-#pragma unroll
-            for (int i = 0; i < CH2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bn + ((long)(j * KS32 + i) << 9));
-                    bl[0][i][j] = *reinterpret_cast<const xa_bf16x8*>(bn + (long)XHJ * C + ((long)(j * KS32 + i) << 9));
-                }
-        }
-    }
-    // the operand of the output product does not depend on the softmax: request it now, it lands during the softmax
-    constexpr int KD = 3;  // heads * L <= 40 -> three 16-deep k-steps cover the (head, key) pairs
-    xa_bf16x8 mh[KD][NT], ml[KD][NT];
-    {
-        const wd_bf16* bm = mot_pl + ((long)b * 2) * C * XHJ + ((long)(cg * NT) * 4 << 9) + lane * 8;  // block (n tile, ks)
-#pragma unroll
-        for (int ks = 0; ks < KD; ++ks)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                mh[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + ((long)(t * 4 + ks) << 9));
-                ml[ks][t] = *reinterpret_cast<const xa_bf16x8*>(bm + (long)C * XHJ + ((long)(t * 4 + ks) << 9));
-            }
-    }
-    __syncthreads();
-    // ---- softmax per (token, head) -> probability planes
-    for (int idx = tid; idx < XT * heads; idx += NTH) {
-        const int t = idx / heads, h = idx - t * heads;
-        const float* pr = sS + t * SP + h * L;
-        float mx = -3.4e38f;
-        for (int j = 0; j < L; ++j) mx = fmaxf(mx, pr[j]);
-        // (hardware exp2: this phase is serial for the workgroup - one wave per SIMD - so its instruction count is latency)
-        float sum = 0.f;
-        for (int j = 0; j < L; ++j) sum += __expf(pr[j] - mx);
-        const float inv = __fdividef(1.f, sum);
-        for (int j = 0; j < L; ++j) {
-            uint32_t hi, lo;
-            wd_split1(__expf(pr[j] - mx) * inv, hi, lo);
-            sP[(long)t * PP + h * L + j] = (wd_bf16)hi;
-            sP[(long)(XT + t) * PP + h * L + j] = (wd_bf16)lo;
-        }
-    }
-    __syncthreads();
-    // ---- output image O[token][n] = P . Mo: wave = (token tile rt, half of the column tiles)
-    {
-        xa_f32x16 o[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-        const wd_bf16* ap = sP + (long)(rt * 32 + l31) * PP + lh * 8;
-#pragma unroll
-        for (int ks = 0; ks < KD; ++ks) {
-            const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ap + ks * 16);
-            const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ap + (long)XT * PP + ks * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, mh[ks][t], o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ml[ks][t], o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, mh[ks][t], o[t], 0, 0, 0);
-            }
-        }
-        // (sX is dead: every wave passed the barrier after the score phase)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sO[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * OP + (cg * NT + t) * 32 + l31] = o[t][r];
-    }
-    __syncthreads();
-    // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
-    {
-        float4 bi[FI];
-#pragma unroll
-        for (int i = 0; i < FI; ++i) bi[i] = *reinterpret_cast<const float4*>(bias + (l15 + 16 * i) * 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = wave * 16 + k * 4 + qd;
-            const bool ok = t < ntok;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const int n = (l15 + 16 * i) * 4;
-                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + n);
-                xr[k][i] = make_float4(at.x + bi[i].x + xr[k][i].x, at.y + bi[i].y + xr[k][i].y, at.z + bi[i].z + xr[k][i].z,
-                                       at.w + bi[i].w + xr[k][i].w);
-                if (ok && last) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
-                s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
-            }
-            if (n_hi && last) {
-                const float mean = wd_row16_sum(s) / (float)C;
-                float q = 0.f;
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
-                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                }
-                const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps2);
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < FI; ++i) {
-                        const int n = (l15 + 16 * i) * 4;
-                        const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + n);
-                        const float4 b2 = *reinterpret_cast<const float4*>(beta2 + n);
-                        float4 y;
-                        y.x = (xr[k][i].x - mean) * rstd * g2.x + b2.x; y.y = (xr[k][i].y - mean) * rstd * g2.y + b2.y;
-                        y.z = (xr[k][i].z - mean) * rstd * g2.z + b2.z; y.w = (xr[k][i].w - mean) * rstd * g2.w + b2.w;
-                        uint2 hi, lo;
-                        wd_split4(y, hi, lo);
-                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + n) = hi;
-                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + n) = lo;
-                    }
-                }
-            }
-        }
-    }
-    if (!last) __syncthreads();  // the output image is consumed before the next attention overwrites the token planes
-    }
-}
-
-template <int NI, int NW, int NP>
-int launch_mfma(const float* x, int ld, int batch, int hw, const XaLayer& la, const XaLayer& lb, float eps, int heads, int L,
-                float* out, int out_ld, const float* gamma2, const float* beta2, float eps2, wd_bf16* n_hi, wd_bf16* n_lo,
-                int n_ld, hipStream_t st) {
-    constexpr int C = NI * 32, XTM = 16 * NW;
-    constexpr size_t xb = (size_t)2 * XTM * (C + 8) * 2 > (size_t)XTM * (C + 4) * 4 ? (size_t)2 * XTM * (C + 8) * 2 : (size_t)XTM * (C + 4) * 4;
-    constexpr size_t smem = xb + (size_t)XTM * (XHJ + 1) * 4 + (size_t)2 * XTM * (XHJ + 8) * 2;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_mfma_kernel<NI, NW, NP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return WD_ELAUNCH;
-        attr = true;
-    }
-    WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((xattn_mfma_kernel<NI, NW, NP>), dim3(batch, (hw + XTM - 1) / XTM), dim3(64 * NW), smem, st, x, ld, hw, la, lb,
-                       eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld);
-    return wd_check_launch();
-}
-
-// ---- 16 tokens per workgroup of two waves: twice the workgroups of xattn_mfma_kernel (B = 64 at 8 x 32: 1024, four per CU = two
-// waves per SIMD) with half the dependent chain each.  The 32-token kernel runs one wave per SIMD, so every memory and LDS latency of
-// its chain (rows -> LayerNorm -> scores -> softmax -> output -> epilogue, twice) is exposed: 128 workgroups took 30 us, 512 took 40.
-//   scores: v_mfma_f32_16x16x32_bf16, the (head, key) tiles of 16 dealt to the waves (wave 0: tiles 0 and 1, wave 1: tile 2);
-//   output: per wave C / 32 column tiles of 16: one 16x16x32 step over hj 0..31 and one 16x16x16 step over hj 32..47.
+// ---- 16 tokens per workgroup of four waves (B = 64 at 8 x 32: 1024 workgroups, three resident per CU).  The kernel this replaces
+// gave 32 tokens to two waves and ran one wave per SIMD, so every memory and LDS latency of its chain (rows -> LayerNorm -> scores
+// -> softmax -> output -> epilogue, twice) was exposed: 128 workgroups (the 4 x 16 level) took 23-30 us, 512 took 32-40; this one
+// takes 11 and 28.  Everything on v_mfma_f32_16x16x32_bf16:
+//   scores: wave w owns the (head, key) tile of 16 number w (heads * L <= 40: three tiles, the fourth wave has none); its three
+//           split products run in three independent accumulators;
+//   output: wave w owns C / 64 column tiles of 16; two k-steps over the (head, key) pairs 0..31 and 32..63 (zero beyond heads * L:
+//           lanes whose 8-pair chunk is all padding do not load).
+// (A 16x16x16 step for the pairs 32..47 would halve the second step, but v_mfma_f32_16x16x16_bf16 is not safe here: the compiler
+// pads s_nop 7 between it and a DS read of its result, the hardware needs more - rows 4 q + {0, 1} of the tile came back stale in
+// the two-attention instantiation until 32 wait states were added by hand.)
 typedef __attribute__((ext_vector_type(4))) float xa_f32x4;
-typedef __attribute__((ext_vector_type(4))) short xa_s16x4;
+
+typedef __attribute__((ext_vector_type(4))) unsigned xa_u32x4;
+__device__ __forceinline__ xa_bf16x8 xa_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(xa_bf16x8, (xa_u32x4)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 template <int NI, int NP, int LL>  // c = NI * 32; NP attentions chained; LL = keys per head when known at compile time (0: run time)
-__global__ void __launch_bounds__(128, 2) xattn16_kernel(const float* __restrict__ x, int ld, int hw, const XaLayer la,
-                                                         const XaLayer lb, float eps, int heads, int L,
-                                                         float* __restrict__ out, int out_ld,
-                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
-                                                         float eps2, wd_bf16* __restrict__ n_hi, wd_bf16* __restrict__ n_lo,
-                                                         int n_ld) {
-    constexpr int XT = 16, NTH = 128;
-    constexpr int C = NI * 32, XP = C + 8, OP = C + 4, SP = 49, PP = 56;
+__global__ void __launch_bounds__(256, 3) xattn16_kernel(const float* __restrict__ x, int ld, int hw, const XaLayer la,
+                                                      const XaLayer lb, float eps, int heads, int L, float* __restrict__ out,
+                                                      int out_ld, const float* __restrict__ gamma2,
+                                                      const float* __restrict__ beta2, float eps2, wd_bf16* __restrict__ n_hi,
+                                                      wd_bf16* __restrict__ n_lo, int n_ld) {
+    constexpr int XT = 16, NTH = 256;
+    constexpr int C = NI * 32, XP = C + 8, OP = C + 4, SP = 65, PP = 72, NT = NI / 2, KS32 = C / 32;
+    static_assert(NI % 2 == 0, "column tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wd_bf16* sX = reinterpret_cast<wd_bf16*>(smem);                              // [2][XT][XP] normalised tokens (planes)
     float* sO = reinterpret_cast<float*>(smem);                                   // [XT][OP] output image (overlays sX)
     constexpr size_t XBYTES = (size_t)2 * XT * XP * 2 > (size_t)XT * OP * 4 ? (size_t)2 * XT * XP * 2 : (size_t)XT * OP * 4;
     float* sS = reinterpret_cast<float*>(smem + XBYTES);                          // [XT][SP] scores
     wd_bf16* sP = reinterpret_cast<wd_bf16*>(smem + XBYTES + (size_t)XT * SP * 4);  // [2][XT][PP] probabilities (planes)
-    const int b = blockIdx.x, t0 = blockIdx.y * XT;  // consecutive workgroup ids = consecutive samples (see xattn_mfma_kernel)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // parameter vectors used after the first barrier, staged once (read from global where they are used, each is an exposed L2
+    // round trip of the chain): [0] la.bias [1] lb.gamma [2] lb.beta [3] lb.bias [4] gamma2 [5] beta2
+    float* sV = reinterpret_cast<float*>(smem + XBYTES + (size_t)XT * SP * 4 + (size_t)2 * XT * PP * 2);  // [6][C]
+    // grid (batch, token tiles): consecutive workgroup ids = consecutive samples, so the token tiles of one sample (which share its
+    // folded matrices) are dealt to the same XCD and find them in its L2
+    const int b = blockIdx.x, t0 = blockIdx.y * XT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the per-wave branches below are s_cbranch)
     const int HJ = heads * L;
     const long row0 = (long)b * hw + t0;
     const int ntok = min(XT, hw - t0);
-    constexpr int FI = NI / 2;  // float4 per lane per row; a row is handled by a quarter wave, eight rows per wave
+    constexpr int FI = NI / 2;  // float4 per lane per row; a row is handled by a quarter wave, four rows per wave
     const int qd = lane >> 4, l15 = lane & 15;
-    float4 xr[2][FI];
+    const int trow = wave * 4 + qd;
+    const bool ok = trow < ntok;
+    float4 xr[FI];
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const int t = wave * 8 + k * 4 + qd;
-            xr[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < ntok) xr[k][i] = *reinterpret_cast<const float4*>(x + (row0 + t) * ld + (l15 + 16 * i) * 4);
-        }
-    constexpr int KS32 = C / 32;
-    constexpr int CH2 = KS32 >= 5 ? 5 : KS32;
-    constexpr int NCH2 = KS32 / CH2;
-    static_assert(KS32 % CH2 == 0, "chunking");
-    // (head, key) tiles of this wave: two for wave 0, the rest (at most one: heads * L <= 40) for wave 1
-    const int ntile = (HJ + 15) >> 4;
-    const int tile0 = wave * 2;
-    const int nj = min(2, max(0, ntile - tile0));
-    xa_bf16x8 bh[2][CH2][2], bl[2][CH2][2];
+    for (int i = 0; i < FI; ++i) {
+        xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) xr[i] = *reinterpret_cast<const float4*>(x + (row0 + trow) * ld + (l15 + 16 * i) * 4);
+    }
+    const bool row_live = wave * 16 + l15 < HJ;   // this lane's row of the wave's (head, key) tile is not padding
     const long pq = (long)XHJ * C;
-    const long bq_off = ((long)b * 2) * pq + ((long)tile0 * KS32 << 9) + lane * 8;  // block (tile0 + j, ks): + (j KS32 + ks) << 9
-    auto request = [&](const wd_bf16* base, auto bufc, int ch) {
-        constexpr int BUF = decltype(bufc)::value;
+    // The whole score operand of this wave's (head, key) tile: 80 registers, requested after the LayerNorm (whose temporaries would
+    // push them to scratch; requested a phase earlier the launch took 31 us instead of 27.8 - the loads then queue behind the row
+    // burst - and the step was no faster).  Raw buffer loads: a lane whose row / chunk is padding gets an out-of-range offset -
+    // zeros, no memory traffic, no branch; straight-line for all four waves (conditional definitions of these registers across a
+    // barrier sent them through scratch).
+    xa_bf16x8 bh[KS32], bl[KS32];
+    auto request_scores = [&](const XaLayer& ly) {
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<wd_bf16*>(ly.mq_pl + (long)b * 2 * pq), 0,
+                                                                            (int)(2 * pq * 2), 0x00020000);
+        const unsigned vo = row_live ? lane * 16u : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < CH2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // (unconditional: a predicated load keeps the register's previous value alive across the whole pass; a tile this
-                // wave does not own re-reads tile0's lines, which its L1 holds)
-                const int jj = j < nj ? j : 0;
-                bh[BUF][i][j] = *reinterpret_cast<const xa_bf16x8*>(base + ((long)(jj * KS32 + ch * CH2 + i) << 9));
-                bl[BUF][i][j] = *reinterpret_cast<const xa_bf16x8*>(base + pq + ((long)(jj * KS32 + ch * CH2 + i) << 9));
-            }
+        for (int ks = 0; ks < KS32; ++ks) {
+            bh[ks] = xa_bload(rq, vo, (unsigned)((wave * KS32 + ks) << 10));
+            bl[ks] = xa_bload(rq, vo, (unsigned)(((wave * KS32 + ks) << 10) + pq * 2));
+        }
     };
-    typedef std::integral_constant<int, 0> B0;
-    typedef std::integral_constant<int, 1> B1;
-    request(la.mq_pl + bq_off, B0(), 0);
     for (int e = tid; e < 2 * XT * PP / 2; e += NTH) reinterpret_cast<uint32_t*>(sP)[e] = 0u;  // padding columns stay zero
+    for (int e = tid; e < 6 * (C / 4); e += NTH) {
+        const int v = e / (C / 4), i = e - v * (C / 4);
+        const float* src = v == 0 ? la.bias : v == 1 ? lb.gamma : v == 2 ? lb.beta : v == 3 ? lb.bias : v == 4 ? gamma2 : beta2;
+        if (src) reinterpret_cast<float4*>(sV)[e] = reinterpret_cast<const float4*>(src)[i];
+    }
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
     const XaLayer& ly = ps == 0 ? la : lb;
-    const float* __restrict__ gamma = ly.gamma;
-    const float* __restrict__ beta = ly.beta;
-    const float* __restrict__ bias = ly.bias;
+    const float* gamma = ps == 0 ? la.gamma : sV + C;      // (first LayerNorm: from global, requested together with the rows)
+    const float* beta = ps == 0 ? la.beta : sV + 2 * C;
+    const float* bias = ps == 0 ? sV : sV + 3 * C;
     const bool last = ps == NP - 1;
-    const wd_bf16* bq = ly.mq_pl + bq_off;
     // ---- LayerNorm -> split planes in LDS
     {
-        float4 ga[FI], be[FI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+        const float mean = wd_row16_sum(s) / (float)C;
+        float q = 0.f;
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
-            ga[i] = *reinterpret_cast<const float4*>(gamma + (l15 + 16 * i) * 4);
-            be[i] = *reinterpret_cast<const float4*>(beta + (l15 + 16 * i) * 4);
+            const float a0 = xr[i].x - mean, a1 = xr[i].y - mean, a2 = xr[i].z - mean, a3 = xr[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }
+        const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = wave * 8 + k * 4 + qd;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
-            const float mean = wd_row16_sum(s) / (float)C;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps);
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                float4 o;
-                o.x = (xr[k][i].x - mean) * rstd * ga[i].x + be[i].x; o.y = (xr[k][i].y - mean) * rstd * ga[i].y + be[i].y;
-                o.z = (xr[k][i].z - mean) * rstd * ga[i].z + be[i].z; o.w = (xr[k][i].w - mean) * rstd * ga[i].w + be[i].w;
-                uint2 hi, lo;
-                wd_split4(o, hi, lo);
-                *reinterpret_cast<uint2*>(sX + (long)t * XP + (l15 + 16 * i) * 4) = hi;
-                *reinterpret_cast<uint2*>(sX + (long)(XT + t) * XP + (l15 + 16 * i) * 4) = lo;
-            }
+        for (int i = 0; i < FI; ++i) {
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + (l15 + 16 * i) * 4);
+            const float4 be = *reinterpret_cast<const float4*>(beta + (l15 + 16 * i) * 4);
+            float4 o;
+            o.x = (xr[i].x - mean) * rstd * ga.x + be.x; o.y = (xr[i].y - mean) * rstd * ga.y + be.y;
+            o.z = (xr[i].z - mean) * rstd * ga.z + be.z; o.w = (xr[i].w - mean) * rstd * ga.w + be.w;
+            uint2 hi, lo;
+            wd_split4(o, hi, lo);
+            *reinterpret_cast<uint2*>(sX + (long)trow * XP + (l15 + 16 * i) * 4) = hi;
+            *reinterpret_cast<uint2*>(sX + (long)(XT + trow) * XP + (l15 + 16 * i) * 4) = lo;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    request_scores(ly);
     __syncthreads();
 
     // ---- scores S[token][hj] = Xn . Mq^T: operand lane (l15 = row of the tile, qd = 8-element k chunk)
-    if (nj > 0) {
-        xa_f32x4 acc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+    if (wave * 16 < HJ) {  // (the wave without a tile leaves the MFMA pipe to the others)
+        xa_f32x4 a_lh = {0.f, 0.f, 0.f, 0.f}, a_hl = a_lh, a_hh = a_lh;
         const wd_bf16* ax = sX + (long)l15 * XP + qd * 8;
 #pragma unroll
-        for (int ch = 0; ch < NCH2; ++ch) {
-            if (ch + 1 < NCH2) {
-                if ((ch + 1) & 1) request(bq, B1(), ch + 1); else request(bq, B0(), ch + 1);
-            }
-#pragma unroll
-            for (int i = 0; i < CH2; ++i) {
-                const int ks = ch * CH2 + i;
-                const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ax + ks * 32);
-                const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ax + (long)XT * XP + ks * 32);
-                if (nj == 2) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][1], acc[1], 0, 0, 0);
-                } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ch & 1][i][0], acc[0], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ch & 1][i][0], acc[0], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ch & 1][i][0], acc[0], 0, 0, 0);
-                }
-            }
+        for (int ks = 0; ks < KS32; ++ks) {
+            const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ax + ks * 32);
+            const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ax + (long)XT * XP + ks * 32);
+            a_lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], a_lh, 0, 0, 0);
+            a_hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], a_hl, 0, 0, 0);
+            a_hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], a_hh, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < nj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sS[(4 * qd + r) * SP + (tile0 + j) * 16 + l15] = acc[j][r];
-            }
+        for (int r = 0; r < 4; ++r) sS[(4 * qd + r) * SP + wave * 16 + l15] = (a_lh[r] + a_hl[r]) + a_hh[r];
     }
     // the operand of the output product does not depend on the softmax: request it now, it lands during the softmax
-    xa_bf16x8 mh0[NI], ml0[NI];
-    xa_s16x4 mh1[NI], ml1[NI];
+    __builtin_amdgcn_sched_barrier(0);  // (not before the score products have consumed their operand: 80 + 80 registers)
+    xa_bf16x8 mh[2][NT], ml[2][NT];
     {
-        const wd_bf16* bm = ly.mot_pl + ((long)b * 2) * pq + (long)(wave * NI) * 768;
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<wd_bf16*>(ly.mot_pl + (long)b * 2 * pq), 0,
+                                                                            (int)(2 * pq * 2), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < NI; ++t) {
-            mh0[t] = *reinterpret_cast<const xa_bf16x8*>(bm + t * 768 + lane * 8);
-            ml0[t] = *reinterpret_cast<const xa_bf16x8*>(bm + pq + t * 768 + lane * 8);
-            mh1[t] = *reinterpret_cast<const xa_s16x4*>(bm + t * 768 + 512 + lane * 4);
-            ml1[t] = *reinterpret_cast<const xa_s16x4*>(bm + pq + t * 768 + 512 + lane * 4);
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned vo = ks * 32 + qd * 8 < HJ ? lane * 16u : 0x80000000u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {  // block (column tile, ks) = ((wave NT + t) 2 + ks) KB
+                mh[ks][t] = xa_bload(rm, vo, (unsigned)((((wave * NT + t) * 2 + ks) << 10)));
+                ml[ks][t] = xa_bload(rm, vo, (unsigned)((((wave * NT + t) * 2 + ks) << 10) + pq * 2));
+            }
         }
     }
     __syncthreads();
@@ -813,82 +474,64 @@ __global__ void __launch_bounds__(128, 2) xattn16_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    // ---- output image O[token][n] = P . Mo: NI column tiles of 16 per wave, independent accumulators
+    // ---- output image O[token][n] = P . Mo: NT column tiles of 16 per wave, independent accumulators
     {
-        xa_f32x4 o[NI];
+        xa_f32x4 o[NT];
 #pragma unroll
-        for (int t = 0; t < NI; ++t)
+        for (int t = 0; t < NT; ++t) o[t] = xa_f32x4{0.f, 0.f, 0.f, 0.f};
+        const wd_bf16* ap = sP + (long)l15 * PP + qd * 8;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[t][r] = 0.f;
-        const wd_bf16* ap = sP + (long)l15 * PP;
-        const xa_bf16x8 ah0 = *reinterpret_cast<const xa_bf16x8*>(ap + qd * 8);
-        const xa_bf16x8 al0 = *reinterpret_cast<const xa_bf16x8*>(ap + (long)XT * PP + qd * 8);
-        const xa_s16x4 ah1 = *reinterpret_cast<const xa_s16x4*>(ap + 32 + qd * 4);
-        const xa_s16x4 al1 = *reinterpret_cast<const xa_s16x4*>(ap + (long)XT * PP + 32 + qd * 4);
+        for (int ks = 0; ks < 2; ++ks) {
+            const xa_bf16x8 ah = *reinterpret_cast<const xa_bf16x8*>(ap + ks * 32);
+            const xa_bf16x8 al = *reinterpret_cast<const xa_bf16x8*>(ap + (long)XT * PP + ks * 32);
 #pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, mh0[t], o[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, mh[ks][t], o[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al1, mh1[t], o[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ml[ks][t], o[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, ml0[t], o[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, mh[ks][t], o[t], 0, 0, 0);
+        }
+        // (sX is dead: every wave passed the barrier after the score phase)
 #pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah1, ml1[t], o[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, mh0[t], o[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NI; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah1, mh1[t], o[t], 0, 0, 0);
-        // (sX is dead: both waves passed the barrier after the score phase)
-#pragma unroll
-        for (int t = 0; t < NI; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sO[(4 * qd + r) * OP + (wave * NI + t) * 16 + l15] = o[t][r];
+            for (int r = 0; r < 4; ++r) sO[(4 * qd + r) * OP + (wave * NT + t) * 16 + l15] = o[t][r];
     }
-    // chunk 0 of the next attention's score operand: lands during the epilogue and the next LayerNorm
-    __builtin_amdgcn_sched_barrier(0);  // (hoisted above the output product these 80 registers would spill)
-    if (NP == 2 && ps == 0) request(lb.mq_pl + bq_off, B0(), 0);
     __syncthreads();
-    // ---- epilogue: + bias + residual (rows still in registers), store, optional following LayerNorm -> planes
+    // ---- epilogue: + bias + residual (the row is still in registers), store, optional following LayerNorm -> planes
     {
-        float4 bi[FI];
+        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < FI; ++i) bi[i] = *reinterpret_cast<const float4*>(bias + (l15 + 16 * i) * 4);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = wave * 8 + k * 4 + qd;
-            const bool ok = t < ntok;
-            float s = 0.f;
+        for (int i = 0; i < FI; ++i) {
+            const int n = (l15 + 16 * i) * 4;
+            const float4 bi = *reinterpret_cast<const float4*>(bias + n);
+            const float4 at = *reinterpret_cast<const float4*>(sO + trow * OP + n);
+            xr[i] = make_float4(at.x + bi.x + xr[i].x, at.y + bi.y + xr[i].y, at.z + bi.z + xr[i].z, at.w + bi.w + xr[i].w);
+            if (ok && last) *reinterpret_cast<float4*>(out + (row0 + trow) * out_ld + n) = xr[i];
+            s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+        }
+        if (n_hi && last) {
+            const float mean = wd_row16_sum(s) / (float)C;
+            float q = 0.f;
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
-                const int n = (l15 + 16 * i) * 4;
-                const float4 at = *reinterpret_cast<const float4*>(sO + t * OP + n);
-                xr[k][i] = make_float4(at.x + bi[i].x + xr[k][i].x, at.y + bi[i].y + xr[k][i].y, at.z + bi[i].z + xr[k][i].z,
-                                       at.w + bi[i].w + xr[k][i].w);
-                if (ok && last) *reinterpret_cast<float4*>(out + (row0 + t) * out_ld + n) = xr[k][i];
-                s += (xr[k][i].x + xr[k][i].y) + (xr[k][i].z + xr[k][i].w);
+                const float a0 = xr[i].x - mean, a1 = xr[i].y - mean, a2 = xr[i].z - mean, a3 = xr[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
-            if (n_hi && last) {
-                const float mean = wd_row16_sum(s) / (float)C;
-                float q = 0.f;
+            const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps2);
+            if (ok) {
 #pragma unroll
                 for (int i = 0; i < FI; ++i) {
-                    const float a0 = xr[k][i].x - mean, a1 = xr[k][i].y - mean, a2 = xr[k][i].z - mean, a3 = xr[k][i].w - mean;
-                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                }
-                const float rstd = 1.0f / sqrtf(wd_row16_sum(q) / (float)C + eps2);
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < FI; ++i) {
-                        const int n = (l15 + 16 * i) * 4;
-                        const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + n);
-                        const float4 b2 = *reinterpret_cast<const float4*>(beta2 + n);
-                        float4 y;
-                        y.x = (xr[k][i].x - mean) * rstd * g2.x + b2.x; y.y = (xr[k][i].y - mean) * rstd * g2.y + b2.y;
-                        y.z = (xr[k][i].z - mean) * rstd * g2.z + b2.z; y.w = (xr[k][i].w - mean) * rstd * g2.w + b2.w;
-                        uint2 hi, lo;
-                        wd_split4(y, hi, lo);
-                        *reinterpret_cast<uint2*>(n_hi + (row0 + t) * n_ld + n) = hi;
-                        if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + t) * n_ld + n) = lo;
-                    }
+                    const int n = (l15 + 16 * i) * 4;
+                    const float4 g2 = *reinterpret_cast<const float4*>(sV + 4 * C + n);
+                    const float4 b2 = *reinterpret_cast<const float4*>(sV + 5 * C + n);
+                    float4 y;
+                    y.x = (xr[i].x - mean) * rstd * g2.x + b2.x; y.y = (xr[i].y - mean) * rstd * g2.y + b2.y;
+                    y.z = (xr[i].z - mean) * rstd * g2.z + b2.z; y.w = (xr[i].w - mean) * rstd * g2.w + b2.w;
+                    uint2 hi, lo;
+                    wd_split4(y, hi, lo);
+                    *reinterpret_cast<uint2*>(n_hi + (row0 + trow) * n_ld + n) = hi;
+                    if (n_lo) *reinterpret_cast<uint2*>(n_lo + (row0 + trow) * n_ld + n) = lo;
                 }
             }
         }
@@ -903,15 +546,17 @@ int launch16(const float* x, int ld, int batch, int hw, const XaLayer& la, const
              hipStream_t st) {
     constexpr int C = NI * 32, XTM = 16;
     constexpr size_t xb = (size_t)2 * XTM * (C + 8) * 2 > (size_t)XTM * (C + 4) * 4 ? (size_t)2 * XTM * (C + 8) * 2 : (size_t)XTM * (C + 4) * 4;
-    constexpr size_t smem = xb + (size_t)XTM * 49 * 4 + (size_t)2 * XTM * 56 * 2;
+    constexpr size_t smem = xb + (size_t)XTM * 65 * 4 + (size_t)2 * XTM * 72 * 2 + (size_t)6 * C * 4;
     static_assert(smem <= 48 * 1024, "static LDS limit");
     WdLaunchScope scope(WD_CLS_ATTN, st);
     const dim3 grid(batch, (hw + XTM - 1) / XTM);
+    // (three workgroups per CU: 145 / 152 registers.  Four - the whole grid of the 8 x 32 level resident at once - spill 10 / 30
+    // registers and ran 33.5 us instead of 27.8.)
     if (L == 10)
-        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 10>), grid, dim3(128), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
+        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 10>), grid, dim3(256), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
                            gamma2, beta2, eps2, n_hi, n_lo, n_ld);
     else
-        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 0>), grid, dim3(128), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
+        hipLaunchKernelGGL((xattn16_kernel<NI, NP, 0>), grid, dim3(256), smem, st, x, ld, hw, la, lb, eps, heads, L, out, out_ld,
                            gamma2, beta2, eps2, n_hi, n_lo, n_ld);
     return wd_check_launch();
 }
@@ -930,7 +575,7 @@ extern "C" int wd_xattn_fold(const float* k, int ldk, const float* v, int ldv, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     hipLaunchKernelGGL(xattn_fold_kernel, dim3(L, heads, batch), dim3(256), 2 * d * sizeof(float), st, k, ldk, v, ldv, heads, L, d,
-                       scale, wq, wo, c, mq, mo, mq_pl, mot_pl, xa_tokens16() ? 1 : 0);
+                       scale, wq, wo, c, mq, mo, mq_pl, mot_pl);
     return wd_check_launch();
 }
 
@@ -943,14 +588,9 @@ extern "C" int wd_xattn_fused(const float* x, int ld, int batch, int hw, int c, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mq_pl && mot_pl && !getenv("WDIFF_XATTN_VALU")) {
         const XaLayer la = {gamma, beta, mq_pl, mot_pl, bias};
-        if (xa_tokens16()) {
-            if (c == 320)
-                return launch16<10, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-            return launch16<2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-        }
         if (c == 320)
-            return launch_mfma<10, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-        return launch_mfma<2, 2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+            return launch16<10, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+        return launch16<2, 1>(x, ld, batch, hw, la, la, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
     }
     const int nh = (heads * L + 7) / 8;
 #define WD_XA(NI_, NH_)                                                                                                     \
@@ -988,14 +628,7 @@ extern "C" int wd_xattn_pair(const float* x, int ld, int batch, int hw, int c, f
     if (!wd_xattn_supported(c, heads, L) || ld % 4 || out_ld % 4 || (n_hi && (n_ld % 4 || !gamma2 || !beta2))) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const XaLayer la = {gamma_a, beta_a, mq_pl_a, mot_pl_a, bias_a}, lb = {gamma_b, beta_b, mq_pl_b, mot_pl_b, bias_b};
-    if (xa_tokens16()) {
-        if (c == 320)
-            return launch16<10, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-        return launch16<2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-    }
-    if (c == 320) {
-        // (64 tokens per workgroup - launch_mfma<10, 4, 2> - halves the operand fetches but leaves one workgroup per CU: 41.4 vs 39.5 us)
-        return launch_mfma<10, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
-    }
-    return launch_mfma<2, 2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+    if (c == 320)
+        return launch16<10, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
+    return launch16<2, 2>(x, ld, batch, hw, la, lb, eps, heads, L, out, out_ld, gamma2, beta2, eps2, n_hi, n_lo, n_ld, st);
 }
