@@ -581,7 +581,8 @@ def test_noise_images_and_ema_exact():
     assert float((ed.cpu() - ref).abs().max()) <= 1e-9 + 2 ** -24 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("B,hw,c,heads,L", [(3, 256, 320, 4, 10), (2, 70, 320, 4, 10), (2, 32, 64, 4, 7), (2, 64, 64, 2, 10)])
+@pytest.mark.parametrize("B,hw,c,heads,L", [(3, 256, 320, 4, 10), (2, 70, 320, 4, 10), (2, 32, 64, 4, 7), (2, 64, 64, 2, 10),
+                                            (2, 48, 320, 8, 5), (2, 20, 64, 2, 5), (1, 5, 320, 4, 9)])
 def test_folded_cross_attention(B, hw, c, heads, L):
     """wd_xattn_fold + wd_xattn_fused == x + to_out(attention(to_q(LN(x)), K, V)) (unet.py:164-279,337-345) and the LayerNorm
     that follows, against fp64 torch."""

@@ -25,6 +25,7 @@ SHAPES = {
     "lin8x32": (8, 32, 320, 320, "lin"),
     "ff1": (8, 32, 320, 2560, "geglu"),
     "ff2": (8, 32, 1280, 320, "lin"),
+    "lin2560": (8, 32, 320, 2560, "lin"),    # ff1 without the GEGLU epilogue: what that epilogue costs
     "lin4x16": (4, 16, 320, 320, "lin"),
     "temb": (1, 1, 1280, 1280, "lin"),
     "lin_k64": (8, 32, 64, 320, "lin"),      # one stage: the fixed cost of a launch (prologue + epilogue)

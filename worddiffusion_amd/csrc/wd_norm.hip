@@ -230,7 +230,10 @@ __global__ void __launch_bounds__(256) gn_conv_few_kernel(const float* __restric
     float* s_w = reinterpret_cast<float*>(smem);   // [GC_CH][9][4]: this chunk's weights
     float* s_t = s_w + 9 * GC_CH * 4;               // [3][W + 2][GC_PITCH]
     __shared__ float s_mean[32], s_rstd[32];
-    const int y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // grid (batch, H): consecutive workgroup ids = consecutive samples, so the rows of one sample - each of which is read by the
+    // workgroups of the rows above and below too - are dealt to the same XCD and re-read from its L2 (with (H, batch) the eight rows
+    // of a sample went to eight XCDs: 58.8 MB fetched for a 21 MB input)
+    const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
     const int hw = H * W, ng = c / cpg;
     // this thread's share of a chunk's three rows: item i = tid + 256 k -> (row r, pixel px, channel quad c4)
     float4 pv[NLD];
@@ -415,10 +418,10 @@ extern "C" int wd_gn_conv3x3_few(const float* x, int ld, int batch, int h, int w
     const size_t smem = (size_t)(9 * GC_CH * 4 + gn_conv_tile_floats(w)) * sizeof(float);  // <= 64 KB: no attribute needed
     WdLaunchScope scope(WD_CLS_OTHER, st);
     if (w <= 32)
-        hipLaunchKernelGGL(gn_conv_few_kernel<32>, dim3(h, batch), dim3(256), smem, st, x, ld, h, w, c, cpg, nchunk, part_cpg, part,
+        hipLaunchKernelGGL(gn_conv_few_kernel<32>, dim3(batch, h), dim3(256), smem, st, x, ld, h, w, c, cpg, nchunk, part_cpg, part,
                            gamma, beta, eps, silu, weight, bias, oc, out);
     else
-        hipLaunchKernelGGL(gn_conv_few_kernel<64>, dim3(h, batch), dim3(256), smem, st, x, ld, h, w, c, cpg, nchunk, part_cpg, part,
+        hipLaunchKernelGGL(gn_conv_few_kernel<64>, dim3(batch, h), dim3(256), smem, st, x, ld, h, w, c, cpg, nchunk, part_cpg, part,
                            gamma, beta, eps, silu, weight, bias, oc, out);
     return wd_check_launch();
 }
