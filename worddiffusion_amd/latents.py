@@ -172,18 +172,13 @@ class CachedLatentDataset:
                            s_id=self._pre[2].index_select(0, sel))
                 if self.phosc_of is not None:
                     out["phosc"] = self._pre[3].index_select(0, sel)
-                if pin and torch.cuda.is_available():
-                    for k in ("latents", "words", "s_id", "phosc"):
-                        if k in out:
-                            out[k] = out[k].pin_memory()
-                yield out
-                continue
-            items = [self[int(i)] for i in idx]
-            out = dict(image_names=[it["image_name"] for it in items], labels=[it["label"] for it in items],
-                       latents=torch.stack([it["latent"] for it in items]), words=torch.stack([it["word"] for it in items]),
-                       s_id=torch.tensor([it["s_id"] for it in items], dtype=torch.int64))
-            if self.phosc_of is not None:
-                out["phosc"] = torch.stack([it["phosc"] for it in items])
+            else:
+                items = [self[int(i)] for i in idx]
+                out = dict(image_names=[it["image_name"] for it in items], labels=[it["label"] for it in items],
+                           latents=torch.stack([it["latent"] for it in items]), words=torch.stack([it["word"] for it in items]),
+                           s_id=torch.tensor([it["s_id"] for it in items], dtype=torch.int64))
+                if self.phosc_of is not None:
+                    out["phosc"] = torch.stack([it["phosc"] for it in items])
             if pin and torch.cuda.is_available():
                 for k in ("latents", "words", "s_id", "phosc"):
                     if k in out:
