@@ -226,11 +226,13 @@ class RecipeBook(dict):
 
 class Act:
     """A token-major fp32 feature map [B*h*w, c] on the device."""
-    __slots__ = ("t", "c", "h", "w", "stats")
+    __slots__ = ("t", "c", "h", "w", "stats", "prod")
 
-    def __init__(self, t, c, h, w, stats=None):
+    def __init__(self, t, c, h, w, stats=None, prod=None):
         self.t, self.c, self.h, self.w = t, c, h, w
         self.stats = stats  # (part tensor [B, nchunk, c / part_cpg, 2] f64, nchunk, part_cpg) once known
+        self.prod = prod    # the WdGemmArgs of the GEMM whose epilogue writes ``t``: a consumer that wants the operand planes of
+        #                     this very tensor asks that epilogue for them instead of launching wd_split
 
 
 class Plan:
@@ -289,6 +291,7 @@ class UNetEngine:
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
+        self.fuse_split = os.environ.get("WDIFF_FUSE_SPLIT", "1") != "0"   # resample inputs: planes from the producer's epilogue
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
@@ -671,19 +674,25 @@ class UNetEngine:
             g2 = self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
                             bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=out,
                             out_ld=cout, want_stats=True)
-        return Act(out, cout, h, w, g2._stats)
+        return Act(out, cout, h, w, g2._stats, prod=g2)
 
     def _resample(self, P, name, mod, x: Act, mode: str, tile: int = 0) -> Act:
         ops = P.step
         B = self._B
         tab, ho, wo = self._table(x.h, x.w, mode)
         pl = self._planes(P, B * x.h * x.w, x.c)
-        ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, B * x.h * x.w, x.c, 0, pl[0].data_ptr(),
-                                        pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
+        pr = x.prod
+        if pr is not None and self.fuse_split and not pr.out_hi and pr.out_f32 == x.t.data_ptr() and pr.n == x.c:
+            # the producing GEMM writes the planes beside its fp32 output (one launch and one pass over the tensor less)
+            pr.out_hi, pr.out_lo = pl[0].data_ptr(), (pl[1].data_ptr() if self.npass == 3 else None)
+            pr.out_pl_ld = x.c
+        else:
+            ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, B * x.h * x.w, x.c, 0, pl[0].data_ptr(),
+                                            pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
         out = self._f32(P, B * ho * wo, mod.cout)
         gg = self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
                         bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True, tile=tile)
-        return Act(out, mod.cout, ho, wo, gg._stats)
+        return Act(out, mod.cout, ho, wo, gg._stats, prod=gg)
 
     def _attention(self, ops, what, q, ldq, k, ldk, v, ldv, heads, nq, nk, d, scale, out_pl, out_f32=None,
                    out_rows=None, out_row0=0):
@@ -821,7 +830,7 @@ class UNetEngine:
         gg = self._gemm(ops, name + ".proj_out", [self._src(xpl, inner)], name + ".po.w", M, hw,
                         bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=out, out_ld=c,
                         want_stats=True)
-        return Act(out, c, h, w, gg._stats)
+        return Act(out, c, h, w, gg._stats, prod=gg)
 
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int, film_steps: int = 0) -> Plan:
