@@ -56,6 +56,22 @@ def test_forward_matches_reference_golden(golden_dir, tag):
     assert err < 1e-4, (tag, err)
 
 
+def test_resample_planes_from_the_producer_epilogue_are_the_split_launch_planes(golden_dir):
+    """Downsample / Upsample inputs: operand planes written by the producing GEMM's epilogue (default) vs a wd_split launch
+    (engine.fuse_split = False): the same bits, one launch less each."""
+    g = load_golden(golden_dir, "fwd_base_full")
+    outs, nops = [], []
+    for fuse in (True, False):
+        m = build(FULL, "base", False, golden_state_dict(g))
+        m.engine.fuse_split = fuse
+        outs.append(call(m, "base", torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]),
+                         torch.from_numpy(g["y"])))
+        P = next(iter(m.engine._plans.values()))
+        nops.append(sum(1 for _, _, what in P.step if what.endswith(":split")))
+    assert nops == [0, 2]
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_forward_blocks_match_oracle_taps(golden_dir):
     """Intermediate activations (every block output) against the oracle on the small config."""
     g = load_golden(golden_dir, "fwd_base_small")
