@@ -104,9 +104,24 @@ typedef struct wd_gemm_args {
                            * ws in ascending slice order and runs the epilogue itself (same bits as the second launch, one
                            * launch less).  Used when the shapes allow it (16-byte aligned operands, n a multiple of the tile) */
     int32_t ntickets;
+    /* GroupNorm of the RESULT in the combine launch (nn.GroupNorm of the consumer, unet.py:427-431 / :161-162, + SiLU): when
+     * gn_gamma != NULL the planes out_hi / out_lo receive SiLU?((result - mean) * rstd * gn_gamma[col] + gn_beta[col]) with the
+     * statistics of (sample, group of gn_cpg channels) instead of the result itself; out_f32 and stat_part are written as
+     * usual.  Only where one combine tile holds whole (sample, group) blocks: hw_out == 64, m % 64 == 0, n % 40 == 0,
+     * 40 % gn_cpg == 0, gn_cpg % stat_cpg == 0, stat_part and ws given, no activation, and the launch must be one that cuts K
+     * (wd_gemm_auto_ksplit(...) > 1 with ksplit = 0) - anything else returns an error rather than skip the norm. */
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int32_t gn_silu;
+    int32_t gn_cpg;
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);
+
+/* The number of K slices wd_gemm picks by itself (ksplit = 0, tile = 0) for an m x n x ktot product with a workspace of
+ * ws_floats floats and no GEGLU: 1 = no cut.  (What a caller needs to know before it asks for the GroupNorm epilogue.) */
+int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats);
 
 /* GroupNorm statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).  x: [B*hw][ld] fp32 with c channels in
  * groups of cpg.  Writes per (sample, chunk, group) partial (sum, sumsq) in double: part[((b*nchunk + j)*(c/cpg) + g)*2],

@@ -72,6 +72,24 @@ def test_resample_planes_from_the_producer_epilogue_are_the_split_launch_planes(
     assert torch.equal(outs[0], outs[1])
 
 
+def test_groupnorm_in_the_combine_launch_equals_the_apply_launch(golden_dir):
+    """4x16 level of the full base model: the GroupNorms whose input comes from a K-cut convolution are applied by that GEMM's
+    combine launch (wd_gemm_args.gn_*, default) instead of a wd_gn_apply launch (engine.fuse_gn = False).  Same statistics in the
+    same summation order, same arithmetic: the outputs agree to rounding of the fused multiply-adds."""
+    g = load_golden(golden_dir, "fwd_base_full")
+    outs, napply = [], []
+    for fuse in (True, False):
+        m = build(FULL, "base", False, golden_state_dict(g))
+        m.engine.fuse_gn = fuse
+        outs.append(call(m, "base", torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]),
+                         torch.from_numpy(g["y"])))
+        P = next(iter(m.engine._plans.values()))
+        napply.append(sum(1 for _, _, what in P.step if what.endswith(":apply")))
+    assert napply[1] - napply[0] >= 6, napply
+    assert max_rel(outs[0].cpu(), outs[1].cpu()) < 2e-6
+    assert max_rel(outs[0].cpu(), g["out"]) < 1e-4
+
+
 def test_forward_blocks_match_oracle_taps(golden_dir):
     """Intermediate activations (every block output) against the oracle on the small config."""
     g = load_golden(golden_dir, "fwd_base_small")

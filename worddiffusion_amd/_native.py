@@ -38,11 +38,13 @@ class WdGemmArgs(C.Structure):
                 ("out_hi", _vp), ("out_lo", _vp), ("out_pl_ld", C.c_int32), ("tile", C.c_int32),
                 ("w_layout", C.c_int32), ("slab_rows", C.c_int32), ("ksplit", C.c_int32), ("ws", _vp),
                 ("ws_floats", C.c_int64), ("stat_part", _vp), ("stat_cpg", C.c_int32), ("dbg", C.c_int32),
-                ("tickets", _vp), ("ntickets", C.c_int32)]
+                ("tickets", _vp), ("ntickets", C.c_int32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_eps", C.c_float),
+                ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32)]
 
 
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
+    "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
     "wd_gn_nchunk": (_i, [_i]),
     "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "wd_gn_fold_chunks": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -1559,6 +1559,140 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
+// Combine + the consumer's GroupNorm for one 64-row x 40-column tile whose rows are ONE sample (hw_out == 64, wd_gemm_args::gn_*):
+// the slabs summed in ascending order, bias / FiLM row / residual, the fp32 result, the (sample, group) statistics - written to
+// stat_part exactly as the ordinary combine writes them (same summation order) - and SiLU?(GroupNorm(result)) as operand planes.
+// A thread's (at most three) rows stay in its registers between the statistics and the normalisation, so the wd_gn_apply
+// launch and its pass over the tensor disappear (ten of them on the 4x16 level of the base UNet).
+__device__ __forceinline__ void wd_reduce_gn_tile(const wd_gemm_args& a, float* ep, const int m0, const int n0, const int tid) {
+    constexpr int BM = 64, BN = 40, Q = BN / 4, NRL = 256 / Q, KEEP = (BM + NRL - 1) / NRL;
+    const int rl = tid / Q, c = (tid - rl * Q) * 4;
+    const bool live = rl < NRL;
+    const int no = n0 + c;
+    const long total = (long)a.m * a.n;
+    float4 v[KEEP];
+    bool ok[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int row = rl + k * NRL;
+        ok[k] = live && row < BM && m0 + row < a.m;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[k]) v[k] = *reinterpret_cast<const float4*>(a.ws + (long)(m0 + row) * a.n + no);
+    }
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+        float4 q[KEEP];
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[k]) q[k] = *reinterpret_cast<const float4*>(a.ws + (long)sp * total + (long)(m0 + rl + k * NRL) * a.n + no);
+        }
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            v[k].x += q[k].x; v[k].y += q[k].y; v[k].z += q[k].z; v[k].w += q[k].w;
+        }
+    }
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f), rv = bx;
+    if (live && a.bias) bx = *reinterpret_cast<const float4*>(a.bias + no);
+    if (live && a.rowvec) rv = *reinterpret_cast<const float4*>(a.rowvec + (long)(m0 / a.hw_out) * a.rowvec_ld + no);
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        if (!ok[k]) continue;
+        const long m = m0 + rl + k * NRL;
+        v[k].x += bx.x; v[k].y += bx.y; v[k].z += bx.z; v[k].w += bx.w;
+        if (a.rowvec) {
+            v[k].x += rv.x; v[k].y += rv.y; v[k].z += rv.z; v[k].w += rv.w;
+        }
+        if (a.resid) {
+            const float4 q = *reinterpret_cast<const float4*>(a.resid + m * a.resid_ld + no);
+            v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w;
+        }
+        ssum.x += v[k].x; ssum.y += v[k].y; ssum.z += v[k].z; ssum.w += v[k].w;
+        ssq.x += v[k].x * v[k].x; ssq.y += v[k].y * v[k].y; ssq.z += v[k].z * v[k].z; ssq.w += v[k].w * v[k].w;
+        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + m * a.out_ld + no) = v[k];
+    }
+    // per-thread column sums -> (group, row lane) -> (group): the order of the ordinary combine
+    float* scr = ep;                                                  // [NRL][BN][2]
+    double* gs = reinterpret_cast<double*>(ep + NRL * BN * 2);        // [BN / stat_cpg][2]
+    if (live) {
+        float* o = scr + (rl * BN + c) * 2;
+        *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
+    }
+    __syncthreads();
+    const int cps = a.stat_cpg, ngt = BN / cps;
+    for (int it = tid; it < ngt * NRL; it += 256) {
+        const int l = it % NRL, g = it / NRL;
+        const float* p = scr + (l * BN + g * cps) * 2;
+        float su = 0.f, sq = 0.f;
+        for (int cc = 0; cc < cps; ++cc) {
+            su += p[2 * cc];
+            sq += p[2 * cc + 1];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every read of this group's span precedes the write-back
+        scr[(l * BN + g * cps) * 2] = su;
+        scr[(l * BN + g * cps) * 2 + 1] = sq;
+    }
+    __syncthreads();
+    if (tid < ngt && n0 + tid * cps < a.n) {
+        double su = 0.0, sq = 0.0;
+        for (int l = 0; l < NRL; ++l) {
+            const float* p = scr + (l * BN + tid * cps) * 2;
+            su += (double)p[0];
+            sq += (double)p[1];
+        }
+        gs[2 * tid] = su;
+        gs[2 * tid + 1] = sq;
+        double* o = a.stat_part + ((long)(m0 / a.hw_out) * (a.n / cps) + n0 / cps + tid) * 2;  // (one chunk per sample: hw_out == BM)
+        o[0] = su;
+        o[1] = sq;
+    }
+    __syncthreads();
+    if (!live) return;
+    // the consumer's groups: gn_cpg channels = gn_cpg / stat_cpg statistics groups (wd_gn_apply's arithmetic)
+    const int gcp = a.gn_cpg, ratio = gcp / cps;
+    float sc[4], sh[4];
+    const float4 ga = *reinterpret_cast<const float4*>(a.gn_gamma + no);
+    const float4 be = *reinterpret_cast<const float4*>(a.gn_beta + no);
+    const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
+    int gprev = -1;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (c + j) / gcp;
+        if (g != gprev) {
+            double ds = 0.0, dq = 0.0;
+            for (int k = 0; k < ratio; ++k) {
+                ds += gs[2 * (g * ratio + k)];
+                dq += gs[2 * (g * ratio + k) + 1];
+            }
+            const double n = (double)a.hw_out * gcp;
+            const double mu = ds / n;
+            double var = dq / n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+            gprev = g;
+        }
+        sc[j] = rstd * gaa[j];
+        sh[j] = bea[j] - mean * sc[j];
+    }
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        if (!ok[k]) continue;
+        const long m = m0 + rl + k * NRL;
+        float4 y;
+        y.x = v[k].x * sc[0] + sh[0]; y.y = v[k].y * sc[1] + sh[1]; y.z = v[k].z * sc[2] + sh[2]; y.w = v[k].w * sc[3] + sh[3];
+        if (a.gn_silu) {
+            y.x = wd_silu(y.x); y.y = wd_silu(y.y); y.z = wd_silu(y.z); y.w = wd_silu(y.w);
+        }
+        uint2 hh, ll;
+        wd_split4(y, hh, ll);
+        *reinterpret_cast<uint2*>(a.out_hi + m * a.out_pl_ld + no) = hh;
+        if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + m * a.out_pl_ld + no) = ll;
+    }
+}
+
 // out = epilogue(sum of the ksplit partial slabs): one workgroup per BM x BN tile sums the slabs in a fixed order into
 // the same fp32 LDS image the in-kernel epilogue uses and then runs that epilogue (statistics included).
 template <int BM, int BN>
@@ -1571,6 +1705,12 @@ __global__ void __launch_bounds__(256) wd_gemm_reduce_kernel(const wd_gemm_args 
     const int tid = threadIdx.x;
     const long total = (long)a.m * a.n;
     const bool v4 = (a.n & 3) == 0;
+    if constexpr (BM == 64 && BN == 40) {
+        if (a.gn_gamma) {  // (the host has checked shapes and alignment: wd_gemm)
+            wd_reduce_gn_tile(a, ep, m0, n0, tid);
+            return;
+        }
+    }
     {
         // the epilogue's vector path can sum the slabs itself (no LDS image, one barrier less, the slab / residual / row-vector
         // loads of a row in flight together); same conditions as its own `vec` test plus aligned slabs
@@ -2423,6 +2563,34 @@ int launch8(const wd_gemm_args& a, hipStream_t st) {
 
 }  // namespace
 
+// the K cut wd_gemm picks by itself: fewer than 128 tiles (or exactly 128 on a long K loop) and at least 8 stages of 64
+static int wd_auto_ksplit(const int tile, const int m, const int n, const int nk64, const long ws_floats) {
+    const int bn = tile % 1000, bm = tile / 1000;
+    const long tiles = (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn);
+    if (!((tiles < 128 || (tiles == 128 && nk64 >= 32)) && nk64 >= 8)) return 1;
+    long sp = 256 / tiles;
+    if (sp > nk64 / 4) sp = nk64 / 4;
+    if (sp > 8) sp = 8;
+    while (sp > 1 && sp * m * n > ws_floats) --sp;
+    return sp > 1 ? (int)sp : 1;
+}
+
+static int wd_auto_tile(const int m, const int n, const int nk64, const bool can_split_base, const long ws_floats) {
+    // 128x160 when N allows it (A is re-read only N/160 times), else 128x64; when that leaves most CUs idle either
+    // cut K across workgroups (needs a workspace and enough K per slice) or fall back to 64x64 tiles.
+    int tile = (n % 160 == 0) ? 128160 : 128064;
+    const long tiles = (long)((m + 127) / 128) * ((n + (tile % 1000) - 1) / (tile % 1000));
+    const bool can_split = can_split_base && nk64 >= 8 && (long)2 * m * n <= ws_floats;
+    if (tiles < 128 && !can_split && m > 64) tile = 64064;
+    return tile;
+}
+
+extern "C" int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats) {
+    if (m <= 0 || n <= 0 || ktot <= 0 || ktot % BK2 || ws_floats <= 0) return 1;
+    const int nk64 = ktot / BK2;
+    return wd_auto_ksplit(wd_auto_tile(m, n, nk64, true, (long)ws_floats), m, n, nk64, (long)ws_floats);
+}
+
 extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
     wd_gemm_args a = *pa;
@@ -2438,6 +2606,19 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (a.tile == 0) a.tile = bm * 1000 + bn;  // keep 128-row panels (no 64x64 fallback)
     }
     if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout == 1)) return WD_EINVAL;
+    if (a.gn_gamma) {
+        // GroupNorm of the result in the combine launch (wd_reduce_gn_tile): whole (sample, group) blocks per 64 x 40 tile
+        if (!a.gn_beta || !a.stat_part || !a.out_hi || !a.ws || a.hw_out != 64 || a.m % 64 || a.n % 160 || a.gn_cpg <= 0 ||
+            40 % a.gn_cpg || a.stat_cpg <= 0 || a.gn_cpg % a.stat_cpg || a.act != WD_ACT_NONE || a.resid_rows || a.w_layout == 1)
+            return WD_EINVAL;
+        if (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) ||
+            ((reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.rowvec) | reinterpret_cast<uintptr_t>(a.resid) |
+              reinterpret_cast<uintptr_t>(a.out_f32) | reinterpret_cast<uintptr_t>(a.ws) | reinterpret_cast<uintptr_t>(a.gn_gamma) |
+              reinterpret_cast<uintptr_t>(a.gn_beta)) & 15) ||
+            ((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7))
+            return WD_EINVAL;
+        a.tickets = nullptr;  // the norm lives in the combine launch
+    }
     if (a.w_layout == 1) {
         a.ksplit = 1;
         a.tickets = nullptr;
@@ -2515,27 +2696,11 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     v2ok = v2ok && a.src[0].ntaps <= 9 && (a.nsrc == 1 || (a.src[1].gather == nullptr && a.src[1].ntaps == 1));
     const int nk64 = a.ktot / BK2;
     int tile = a.tile;
-    if (tile == 0) {
-        // 128x160 when N allows it (A is re-read only N/160 times), else 128x64; when that leaves most CUs idle either
-        // cut K across workgroups (needs a workspace and enough K per slice) or fall back to 64x64 tiles.
-        tile = (a.n % 160 == 0) ? 128160 : 128064;
-        const long tiles = (long)((a.m + 127) / 128) * ((a.n + (tile % 1000) - 1) / (tile % 1000));
-        const bool can_split = v2ok && a.ws && a.ksplit == 0 && a.act != WD_ACT_GEGLU && nk64 >= 8 &&
-                               (long)2 * a.m * a.n <= a.ws_floats;
-        if (tiles < 128 && !can_split && a.m > 64) tile = 64064;
-    }
+    if (tile == 0)
+        tile = wd_auto_tile(a.m, a.n, nk64, v2ok && a.ws && a.ksplit == 0 && a.act != WD_ACT_GEGLU, a.ws_floats);
     if (a.ksplit == 0) {
-        a.ksplit = 1;
-        const int bn = tile % 1000, bm = tile / 1000;
-        const long tiles = (long)((a.m + bm - 1) / bm) * ((a.n + bn - 1) / bn);
-        // half-filled chip (exactly 128 tiles, e.g. batch 32): a two-way cut pays on the long-K convolutions only
-        if (v2ok && a.ws && a.act != WD_ACT_GEGLU && (tiles < 128 || (tiles == 128 && nk64 >= 32)) && nk64 >= 8) {
-            long sp = 256 / tiles;
-            if (sp > nk64 / 4) sp = nk64 / 4;
-            if (sp > 8) sp = 8;
-            while (sp > 1 && sp * a.m * a.n > a.ws_floats) --sp;
-            if (sp > 1) a.ksplit = (int)sp;
-        }
+        // (half-filled chip - exactly 128 tiles, e.g. batch 32 -: a two-way cut pays on the long-K convolutions only)
+        a.ksplit = (v2ok && a.ws && a.act != WD_ACT_GEGLU) ? wd_auto_ksplit(tile, a.m, a.n, nk64, a.ws_floats) : 1;
     }
     if (a.act == WD_ACT_GEGLU && a.n % (tile % 1000)) return WD_EINVAL;
     if (a.ksplit > 1 && (!v2ok || nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
@@ -2564,6 +2729,8 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (!((fuse_env || (a.dbg & 0x2000)) && a.tickets && a.ksplit > 1 && v2ok && !use_v4 && !conv3 && aligned && ntile <= a.ntickets))
             a.tickets = nullptr;
     }
+    // the GroupNorm epilogue exists in the combine launch of the 128 x 160 kernels only: anything else is an error, not a skipped norm
+    if (a.gn_gamma && !(a.ksplit > 1 && tile == 128160 && v2ok && !use_v4 && !conv3)) return WD_EINVAL;
     static const int ks_env = getenv("WDIFF_GEMM_KS") ? atoi(getenv("WDIFF_GEMM_KS")) : 2;
     const int ks = ks_env == 1 ? 1 : 2;
     static const int stagger_min = getenv("WDIFF_GEMM_STAGGER_MIN") ? atoi(getenv("WDIFF_GEMM_STAGGER_MIN")) : 10;
@@ -2587,7 +2754,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
                 // ring kernel with dedicated loader waves (wd_gemm8_kernel): within +-5 % of the default kernel on every shape; no
                 // fused GroupNorm statistics (its 768-thread epilogue would need a larger statistics scratch).  WDIFF_GEMM_V8=1 takes it wherever legal, dbg 0x80000 forces it (parity tests).
                 static const int v8_env = getenv("WDIFF_GEMM_V8") ? atoi(getenv("WDIFF_GEMM_V8")) : 0;
-                bool v8ok = a.ktot % 32 == 0 && a.src[0].ntaps <= 9 && !a.stat_part && a.act != WD_ACT_GEGLU &&
+                bool v8ok = a.ktot % 32 == 0 && a.src[0].ntaps <= 9 && !a.stat_part && !a.gn_gamma && a.act != WD_ACT_GEGLU &&
                             (a.nsrc == 1 || (a.src[1].gather == nullptr && a.src[1].ntaps == 1));
                 for (int s8 = 0; s8 < a.nsrc; ++s8) v8ok = v8ok && (a.src[s8].c % 32 == 0);
                 if (v8ok && (v8_env == 1 || (a.dbg & 0x80000))) {

@@ -291,6 +291,7 @@ class UNetEngine:
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
+        self.fuse_gn = os.environ.get("WDIFF_FUSE_GN", "1") != "0"         # GroupNorm in the producer's split-K combine launch
         self.fuse_split = os.environ.get("WDIFF_FUSE_SPLIT", "1") != "0"   # resample inputs: planes from the producer's epilogue
         self._plans: Dict[tuple, Plan] = {}
         self._tabs: Dict[tuple, torch.Tensor] = {}
@@ -634,13 +635,37 @@ class UNetEngine:
                 ops.append((self.lib.wd_gn_fold_chunks, (part.data_ptr(), B, nchunk, ngs, folded.data_ptr()), what + ":fold chunks"))
                 part, nchunk = folded, 1
                 s.stats = (part, nchunk, pc)
-            ops.append((self.lib.wd_gn_apply,
-                        (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(),
-                         bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None,
-                         ctot, coff, raw[0].data_ptr() if raw is not None else None,
-                         raw[1].data_ptr() if (raw is not None and self.npass == 3) else None), what + ":apply"))
+            if self._gn_in_combine(s, raw, hw, cpg, pc, nchunk, coff):
+                # the producer is a K-cut GEMM whose combine tiles (64 rows x 40 columns) hold whole (sample, group) blocks: its
+                # combine launch normalises the rows it has just summed and writes these planes (wd_gemm_args.gn_*)
+                pr = s.prod
+                pr.gn_gamma, pr.gn_beta = gam.data_ptr() + 4 * coff, bet.data_ptr() + 4 * coff
+                pr.gn_eps, pr.gn_silu, pr.gn_cpg = float(eps), int(silu), cpg
+                pr.out_hi = pl[0].data_ptr() + 2 * coff
+                pr.out_lo = (pl[1].data_ptr() + 2 * coff) if self.npass == 3 else None
+                pr.out_pl_ld = ctot
+            else:
+                ops.append((self.lib.wd_gn_apply,
+                            (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(),
+                             bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None,
+                             ctot, coff, raw[0].data_ptr() if raw is not None else None,
+                             raw[1].data_ptr() if (raw is not None and self.npass == 3) else None), what + ":apply"))
             coff += s.c
         return pl, raw
+
+    def _gn_in_combine(self, s: Act, raw, hw, cpg, pc, nchunk, coff) -> bool:
+        """Can the GEMM that produced ``s`` apply this GroupNorm in its split-K combine launch (wd_gemm_args.gn_*)?  The
+        conditions of include/wdiff_hip.h, checked here so that the plan never asks for what wd_gemm would refuse."""
+        pr = s.prod
+        if pr is None or not self.fuse_gn or raw is not None or self.use_conv3:
+            return False
+        if pr.out_f32 != s.t.data_ptr() or pr.out_hi or pr.gn_gamma or pr.n != s.c or not pr.stat_part or not pr.ws:
+            return False
+        if hw != 64 or pr.hw_out != 64 or pr.m % 64 or s.c % 160 or 40 % cpg or cpg % pc or nchunk != 1 or coff % 4:
+            return False
+        if pr.act != N.ACT_NONE or pr.resid_rows or pr.ksplit != 0 or pr.tile != 0 or pr.w_layout == 1 or pr.dbg:
+            return False
+        return self.lib.wd_gemm_auto_ksplit(pr.m, pr.n, pr.ktot, pr.ws_floats) > 1
 
     def _ln(self, P, ops, what, x: torch.Tensor, rows, c, name):
         pl = self._planes(P, rows, c)
@@ -664,7 +689,7 @@ class UNetEngine:
         g1 = self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
                         bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
                         rowvec_ld=self.film_total, out_f32=h1, out_ld=cout, want_stats=True)
-        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w, g1._stats)], name + ".gn2", 1e-5, True)
+        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w, g1._stats, prod=g1)], name + ".gn2", 1e-5, True)
         out = self._f32(P, M, cout)
         if need_raw:
             g2 = self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
