@@ -733,3 +733,84 @@ def test_gn_silu_conv3x3_few_output_channels(B, h, w, c, oc, silu):
     torch.cuda.synchronize()
     assert max_rel(out.cpu(), ref) < 2e-6
     assert not lib.wd_gn_conv3x3_few_supported(c, 65, oc) and not lib.wd_gn_conv3x3_few_supported(c, w, 5)
+
+
+@pytest.mark.parametrize("B,cin,cout,cpg,silu,film,resid", [(64, 320, 320, 10, 1, True, False), (5, 64, 320, 20, 0, False, True),
+                                                             (16, 128, 160, 40, 1, False, False)])
+def test_gemm_groupnorm_in_the_combine_launch(B, cin, cout, cpg, silu, film, resid):
+    """wd_gemm_args.gn_*: a K-cut 3x3 convolution over 4x16 images whose combine launch also applies the consumer's GroupNorm
+    (+SiLU) and writes it as operand planes - vs conv -> (+FiLM / +residual) -> F.group_norm -> SiLU in fp64; the fp32 result
+    and the (sample, group) statistics are still written.  Requests the shapes cannot serve are errors, not skipped norms."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B + cin + cout)
+    h, w = 4, 16
+    hw, m = h * w, B * h * w
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fl = torch.randn(B, cout, generator=g) * 0.3 if film else None
+    rs = torch.randn(m, cout, generator=g) if resid else None
+    gam, bet = torch.randn(cout, generator=g) * 0.2 + 1, torch.randn(cout, generator=g) * 0.2
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    if film:
+        ref = ref + fl.double()[:, :, None, None]
+    if resid:
+        ref = ref + rs.double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    refn = F.group_norm(ref, cout // cpg, gam.double(), bet.double(), 1e-5)
+    if silu:
+        refn = F.silu(refn)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(m, -1)  # noqa: E731
+    tab, _, _ = conv_gather_table(h, w, "same")
+    pl = planes_of(tok(x).contiguous().to(DEV))
+    wp = planes_of(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(DEV))
+    tabd = torch.from_numpy(tab).to(DEV)
+    pc = 10 if cpg % 10 == 0 else cpg  # the statistics groups may be finer than the consumer's groups
+
+    def args_for(gn: bool, ksplit=0):
+        a = N.WdGemmArgs()
+        s = N.WdSrc()
+        s.hi, s.lo, s.gather = pl[0].data_ptr(), pl[1].data_ptr(), tabd.data_ptr()
+        s.ld, s.c, s.ntaps, s.hw_src = cin, cin, 9, hw
+        a.src[0] = s
+        a.nsrc, a.npass = 1, 3
+        a.w_hi, a.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
+        a.m, a.n, a.ktot, a.hw_out = m, cout, 9 * cin, hw
+        a.ksplit = ksplit
+        keep = dict(bias=bias.to(DEV), out=torch.full((m, cout), float("nan"), device=DEV),
+                    opl=torch.zeros(2, m, cout, dtype=torch.bfloat16, device=DEV), ws=torch.empty(8 * m * cout, device=DEV),
+                    part=torch.zeros(B, 1, cout // pc, 2, dtype=torch.float64, device=DEV), gam=gam.to(DEV), bet=bet.to(DEV))
+        a.bias = keep["bias"].data_ptr()
+        if film:
+            keep["fl"] = fl.to(DEV)
+            a.rowvec, a.rowvec_ld = keep["fl"].data_ptr(), cout
+        if resid:
+            keep["rs"] = rs.to(DEV)
+            a.resid, a.resid_ld = keep["rs"].data_ptr(), cout
+        a.out_f32, a.out_ld = keep["out"].data_ptr(), cout
+        a.out_hi, a.out_lo, a.out_pl_ld = keep["opl"][0].data_ptr(), keep["opl"][1].data_ptr(), cout
+        a.ws, a.ws_floats = keep["ws"].data_ptr(), keep["ws"].numel()
+        a.stat_part, a.stat_cpg = keep["part"].data_ptr(), pc
+        if gn:
+            a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_silu, a.gn_cpg = keep["gam"].data_ptr(), keep["bet"].data_ptr(), 1e-5, silu, cpg
+        return a, keep
+
+    cut = lib.wd_gemm_auto_ksplit(m, cout, 9 * cin, 8 * m * cout)
+    a, k = args_for(True)
+    rc = lib.wd_gemm(C.byref(a), _st())
+    if cut <= 1:  # (B = 64 at cout = 320 fills the chip: 64 tiles x 4; a tiny batch may not be cut at all)
+        assert rc != 0
+        return
+    N.check(rc, "wd_gemm + GroupNorm")
+    torch.cuda.synchronize()
+    assert max_rel(k["out"].cpu(), tok(ref)) < 2e-5
+    assert max_rel(unplanes(k["opl"]).cpu(), tok(refn)) < 3e-5
+    # statistics as the ordinary combine writes them
+    a0, k0 = args_for(False)
+    N.check(lib.wd_gemm(C.byref(a0), _st()), "wd_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(k["out"], k0["out"])
+    assert torch.allclose(k["part"], k0["part"], rtol=1e-12, atol=0)
+    assert max_rel(unplanes(k0["opl"]).cpu(), tok(ref)) < 2e-5   # without gn_*: the planes hold the result itself
+    # not a K-cut launch -> error
+    a1, _k1 = args_for(True, ksplit=1)
+    assert lib.wd_gemm(C.byref(a1), _st()) != 0
