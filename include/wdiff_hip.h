@@ -142,6 +142,14 @@ int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, const
                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int c_off,
                 wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);
 
+/* The same over the channel concat of TWO tensors (the decoder ResBlocks: [h | skip], unet.py:1586-1588 + :427-431) in one
+ * launch: source a fills columns [c_off_a, c_off_a + ca) of the planes, source b [c_off_b, c_off_b + cb); gamma / beta are
+ * indexed by the concat channel. */
+int wd_gn_apply2(const float* xa, int lda, int ca, const double* part_a, int nchunk_a, int part_cpg_a, int c_off_a,
+                 const float* xb, int ldb, int cb, const double* part_b, int nchunk_b, int part_cpg_b, int c_off_b,
+                 int batch, int hw, int cpg, const float* gamma, const float* beta, float eps, int silu,
+                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);
+
 /* out[b][o][y][x] (NCHW, o < oc <= 4) = Conv3x3(SiLU?(GroupNorm(x)))[o] + bias[o] in one launch, fp32 VALU: the UNet's last layer
  * (GroupNorm32, SiLU, conv 320 -> 4; unet.py:1453-1458) and any other few-output-channel 3x3 (pad 1, stride 1).
  * x: token-major fp32 [batch*h*w][ld]; part / nchunk / part_cpg: GroupNorm statistics as for wd_gn_apply; weight: the

@@ -90,6 +90,22 @@ def test_groupnorm_in_the_combine_launch_equals_the_apply_launch(golden_dir):
     assert max_rel(outs[0].cpu(), g["out"]) < 1e-4
 
 
+def test_two_source_groupnorm_in_one_launch_equals_two_launches(golden_dir):
+    """GroupNorm over [h | skip] (decoder ResBlocks): wd_gn_apply2 (default) vs one wd_gn_apply per source (engine.fuse_gn2 = False):
+    the same arithmetic per element, the same bits."""
+    g = load_golden(golden_dir, "fwd_base_full")
+    outs, napply = [], []
+    for fuse in (True, False):
+        m = build(FULL, "base", False, golden_state_dict(g))
+        m.engine.fuse_gn2 = fuse
+        outs.append(call(m, "base", torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]),
+                         torch.from_numpy(g["y"])))
+        P = next(iter(m.engine._plans.values()))
+        napply.append(sum(1 for _, _, what in P.step if what.endswith(":apply")))
+    assert napply[1] - napply[0] == 4, napply
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_forward_blocks_match_oracle_taps(golden_dir):
     """Intermediate activations (every block output) against the oracle on the small config."""
     g = load_golden(golden_dir, "fwd_base_small")

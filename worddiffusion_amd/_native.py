@@ -51,6 +51,8 @@ _SIGS = {
     "wd_gn_conv3x3_few_supported": (_i, [_i, _i, _i]),
     "wd_gn_conv3x3_few": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "wd_gn_apply": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "wd_gn_apply2": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp,
+                          _vp, _vp]),
     "wd_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wd_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "wd_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),

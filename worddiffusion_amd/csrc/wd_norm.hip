@@ -46,11 +46,21 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int ld, int hw, int
 
 // grid (ceil(hw / TOK_PER_WG), batch), block 256.  One float4 (4 channels) per thread per step.
 constexpr int AP_TOK = 8;
-__global__ void gn_apply_kernel(const float* __restrict__ x, int ld, int hw, int c, int cpg, int nchunk, int part_cpg,
-                                const double* __restrict__ part, const float* __restrict__ gamma,
+struct GnSrc {  // one source tensor of a GroupNorm over a channel concat: its rows, its statistics, its channel offset in the concat
+    const float* x;
+    const double* part;
+    int ld, c, nchunk, part_cpg, c_off;
+};
+
+// grid (token tiles, batch, sources): blockIdx.z picks the source
+__global__ void gn_apply_kernel(const GnSrc s0, const GnSrc s1, int hw, int cpg, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, wd_bf16* __restrict__ out_hi,
-                                wd_bf16* __restrict__ out_lo, int out_ld, int c_off, wd_bf16* __restrict__ raw_hi,
+                                wd_bf16* __restrict__ out_lo, int out_ld, wd_bf16* __restrict__ raw_hi,
                                 wd_bf16* __restrict__ raw_lo) {
+    const GnSrc& sr = blockIdx.z ? s1 : s0;
+    const float* __restrict__ x = sr.x;
+    const double* __restrict__ part = sr.part;
+    const int ld = sr.ld, c = sr.c, nchunk = sr.nchunk, part_cpg = sr.part_cpg, c_off = sr.c_off;
     __shared__ float s_mean[32], s_rstd[32];
     const int b = blockIdx.y;
     const int ng = c / cpg;
@@ -396,8 +406,27 @@ extern "C" int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int
     if (c % 4 || ld % 4 || out_ld % 4 || c_off % 4 || c % cpg || c / cpg > 32 || cpg % part_cpg) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_GNAPPLY, st);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch), dim3(256), 0, st, x, ld, hw, c, cpg,
-                       nchunk, part_cpg, part, gamma, beta, eps, silu, out_hi, out_lo, out_ld, c_off, raw_hi, raw_lo);
+    const GnSrc s0 = {x, part, ld, c, nchunk, part_cpg, c_off};
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch, 1), dim3(256), 0, st, s0, s0, hw, cpg, gamma, beta, eps,
+                       silu, out_hi, out_lo, out_ld, raw_hi, raw_lo);
+    return wd_check_launch();
+}
+
+extern "C" int wd_gn_apply2(const float* xa, int lda, int ca, const double* part_a, int nchunk_a, int part_cpg_a, int c_off_a,
+                            const float* xb, int ldb, int cb, const double* part_b, int nchunk_b, int part_cpg_b, int c_off_b,
+                            int batch, int hw, int cpg, const float* gamma, const float* beta, float eps, int silu,
+                            wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream) {
+    if (!xa || !xb || !part_a || !part_b || !gamma || !beta || !out_hi || batch <= 0 || hw <= 0 || nchunk_a <= 0 || nchunk_b <= 0 ||
+        part_cpg_a <= 0 || part_cpg_b <= 0)
+        return WD_EINVAL;
+    if (ca % 4 || cb % 4 || lda % 4 || ldb % 4 || out_ld % 4 || c_off_a % 4 || c_off_b % 4 || ca % cpg || cb % cpg ||
+        ca / cpg > 32 || cb / cpg > 32 || cpg % part_cpg_a || cpg % part_cpg_b)
+        return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_GNAPPLY, st);
+    const GnSrc s0 = {xa, part_a, lda, ca, nchunk_a, part_cpg_a, c_off_a}, s1 = {xb, part_b, ldb, cb, nchunk_b, part_cpg_b, c_off_b};
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch, 2), dim3(256), 0, st, s0, s1, hw, cpg, gamma, beta, eps,
+                       silu, out_hi, out_lo, out_ld, raw_hi, raw_lo);
     return wd_check_launch();
 }
 

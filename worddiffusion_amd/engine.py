@@ -291,6 +291,7 @@ class UNetEngine:
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
+        self.fuse_gn2 = os.environ.get("WDIFF_FUSE_GN2", "1") != "0"       # GroupNorm over [h | skip]: one apply launch for both
         self.fuse_gn = os.environ.get("WDIFF_FUSE_GN", "1") != "0"         # GroupNorm in the producer's split-K combine launch
         self.fuse_split = os.environ.get("WDIFF_FUSE_SPLIT", "1") != "0"   # resample inputs: planes from the producer's epilogue
         self._plans: Dict[tuple, Plan] = {}
@@ -624,6 +625,7 @@ class UNetEngine:
                 s.stats = (part, nchunk, pc)
         coff = 0
         gam, bet = self._w[gname + ".g"], self._w[gname + ".b"]
+        todo = []  # (source, part, nchunk, pc, coff) of the sources that need an apply launch
         for s in srcs:
             part, nchunk, pc = s.stats
             assert cpg % pc == 0, (what, cpg, pc)
@@ -645,12 +647,22 @@ class UNetEngine:
                 pr.out_lo = (pl[1].data_ptr() + 2 * coff) if self.npass == 3 else None
                 pr.out_pl_ld = ctot
             else:
-                ops.append((self.lib.wd_gn_apply,
-                            (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(),
-                             bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), pl[1].data_ptr() if self.npass == 3 else None,
-                             ctot, coff, raw[0].data_ptr() if raw is not None else None,
-                             raw[1].data_ptr() if (raw is not None and self.npass == 3) else None), what + ":apply"))
+                todo.append((s, part, nchunk, pc, coff))
             coff += s.c
+        lo = pl[1].data_ptr() if self.npass == 3 else None
+        rhi = raw[0].data_ptr() if raw is not None else None
+        rlo = raw[1].data_ptr() if (raw is not None and self.npass == 3) else None
+        if len(todo) == 2 and self.fuse_gn2:  # [h | skip] of a decoder block: one launch for both halves of the concat
+            (sa, pa, na, pca, ca), (sb, pb, nb_, pcb, cb) = todo
+            ops.append((self.lib.wd_gn_apply2,
+                        (sa.t.data_ptr(), sa.c, sa.c, pa.data_ptr(), na, pca, ca, sb.t.data_ptr(), sb.c, sb.c, pb.data_ptr(), nb_, pcb, cb,
+                         B, hw, cpg, gam.data_ptr(), bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), lo, ctot, rhi, rlo),
+                        what + ":apply"))
+        else:
+            for s, part, nchunk, pc, c0 in todo:
+                ops.append((self.lib.wd_gn_apply,
+                            (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(), bet.data_ptr(), eps,
+                             int(silu), pl[0].data_ptr(), lo, ctot, c0, rhi, rlo), what + ":apply"))
         return pl, raw
 
     def _gn_in_combine(self, s: Act, raw, hw, cpg, pc, nchunk, coff) -> bool:
