@@ -122,6 +122,8 @@ int wd_gemm(const wd_gemm_args* args, void* stream);
 /* The number of K slices wd_gemm picks by itself (ksplit = 0, tile = 0) for an m x n x ktot product with a workspace of
  * ws_floats floats and no GEGLU: 1 = no cut.  (What a caller needs to know before it asks for the GroupNorm epilogue.) */
 int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats);
+/* sizeof(wd_gemm_args) as this library was built: a binding that mirrors the struct (ctypes, cgo, ...) compares its own. */
+int wd_gemm_args_bytes(void);
 
 /* GroupNorm statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).  x: [B*hw][ld] fp32 with c channels in
  * groups of cpg.  Writes per (sample, chunk, group) partial (sum, sumsq) in double: part[((b*nchunk + j)*(c/cpg) + g)*2],

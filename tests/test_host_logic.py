@@ -132,6 +132,8 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, sym), sym
     assert set(N._SIGS) == set(declared)
     assert b"gfx950" in N.lib().wd_version()
+    # the ctypes mirror of wd_gemm_args has the library's layout (N.lib() refuses to load a library where it has not)
+    assert N.lib().wd_gemm_args_bytes() == ctypes.sizeof(N.WdGemmArgs)
 
 
 def test_label_padding_and_schedule(golden_dir):

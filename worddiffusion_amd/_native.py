@@ -45,6 +45,7 @@ class WdGemmArgs(C.Structure):
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
     "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
+    "wd_gemm_args_bytes": (_i, []),
     "wd_gn_nchunk": (_i, [_i]),
     "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "wd_gn_fold_chunks": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -145,6 +146,9 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if l.wd_gemm_args_bytes() != C.sizeof(WdGemmArgs):  # a stale library beside newer Python (or the reverse)
+        raise NativeError(f"{LIB_PATH}: wd_gemm_args is {l.wd_gemm_args_bytes()} bytes in the library, {C.sizeof(WdGemmArgs)} in "
+                          "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     _lib = l
     return l
 

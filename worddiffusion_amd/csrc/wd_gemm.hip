@@ -2585,6 +2585,8 @@ static int wd_auto_tile(const int m, const int n, const int nk64, const bool can
     return tile;
 }
 
+extern "C" int wd_gemm_args_bytes(void) { return (int)sizeof(wd_gemm_args); }  // (callers that mirror the struct check their layout)
+
 extern "C" int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats) {
     if (m <= 0 || n <= 0 || ktot <= 0 || ktot % BK2 || ws_floats <= 0) return 1;
     const int nk64 = ktot / BK2;
