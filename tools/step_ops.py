@@ -13,8 +13,9 @@ from worddiffusion_amd import _native as N  # noqa: E402
 
 dev = torch.device("cuda:0")
 batch = int(os.environ.get("BATCH", "64"))
-model, args = B.build_model(dev, "bf16x3", "base")
-run = B.StepRunner(model, args, dev, batch, 0, 0)
+variant = os.environ.get("VARIANT", "base")  # "phosc": UNetModelPhosc with the 769-int PHOSC vector
+model, args = B.build_model(dev, "bf16x3", variant)
+run = B.StepRunner(model, args, dev, batch, 0, 0, phosc_len=769 if variant == "phosc" else 0)
 P, st = run.P, run.stream.cuda_stream
 REP = 20
 rows = []
