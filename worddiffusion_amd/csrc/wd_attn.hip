@@ -232,7 +232,11 @@ __device__ __forceinline__ void fa_split8(const float* f, fa_bf16x8& hi, fa_bf16
     lo = *reinterpret_cast<const fa_bf16x8*>(&lv);
 }
 
-template <int KS, int DVT>
+// KSPLIT: 64 queries per workgroup instead of 128 - the wave pairs {0, 1} and {2, 3} own the SAME 64 queries and take the even /
+// odd 32-key sub-blocks of every LDS block; their (max, sum, O) states are merged once at the end (the flash-decoding merge).  For
+// maps of <= 64 positions (4x16 level) the 128-query form left half of every MFMA tile empty and 256 workgroups to stream 779 keys
+// each: 74.6 us for a quarter of the work the 8x32 level does in 102.
+template <int KS, int DVT, bool KSPLIT>
 __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         int ldk, const float* __restrict__ v, int ldv, int heads, int nq,
                                                         int nk, float scale, float* __restrict__ out_f32,
@@ -249,14 +253,18 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
     wd_bf16* sV = sK + 2 * FA_KB * KP;                // [2 planes][DVR][VP]
     // grid (heads, batch, query tiles): the query tiles of one (sample, head) share K/V - consecutive workgroup ids are
     // different (sample, head) pairs, so those tiles land on the same XCD (ids 8 apart... see launch) and hit its L2
-    const int b = blockIdx.y, h = blockIdx.x, q0 = blockIdx.z * FA_QB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int QB = KSPLIT ? FA_QB / 2 : FA_QB;
+    const int b = blockIdx.y, h = blockIdx.x, q0 = blockIdx.z * QB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = KSPLIT ? (wave & 1) : wave;   // which 32 queries of the tile
+    const int kgrp = KSPLIT ? (wave >> 1) : 0;   // which 32-key sub-block of every 64-key block
     const int l31 = lane & 31, lh = lane >> 5;
 
     // Q fragments (B operand of S^T = K . Q^T), scaled by softmax_scale * log2(e) so that the exponentials are exp2
     fa_bf16x8 qh[KS], ql[KS];
     {
-        const int qi = q0 + wave * 32 + l31;
+        const int qi = q0 + qw * 32 + l31;
         const float sc = scale * 1.44269504088896340736f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -317,6 +325,7 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
         for (int sub = 0; sub < FA_KB / 32; ++sub) {
             const int k0 = kb + sub * 32;
             if (k0 >= nk) break;  // uniform over the workgroup
+            if (KSPLIT && sub != kgrp) continue;  // (wave-uniform) the other wave pair's sub-block
             fa_f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -368,18 +377,46 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / lsum;
     __syncthreads();
-    float* sO = reinterpret_cast<float*>(smem);  // [FA_QB][OP]
+    if constexpr (KSPLIT) {
+        // merge the two key groups' states of every query (lane-for-lane: both pairs hold the same query in the same lane)
+        float* sM = reinterpret_cast<float*>(smem);  // [2 query waves][DVT * 16 + 2][64 lanes]
+        constexpr int NV = DVT * 16 + 2;
+        float* mine = sM + ((long)qw * NV) * 64 + lane;
+        if (kgrp == 1) {
 #pragma unroll
-    for (int t = 0; t < DVT; ++t)
+            for (int t = 0; t < DVT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (dv < D) sO[(wave * 32 + l31) * OP + dv] = o[t][r] * inv;
+                for (int r = 0; r < 16; ++r) mine[(t * 16 + r) * 64] = o[t][r];
+            mine[(DVT * 16) * 64] = m;
+            mine[(DVT * 16 + 1) * 64] = lsum;
         }
+        __syncthreads();
+        if (kgrp == 0) {
+            const float m1 = mine[(DVT * 16) * 64], l1 = mine[(DVT * 16 + 1) * 64];
+            const float mt = fmaxf(m, m1);
+            const float a0 = exp2f(m - mt), a1 = exp2f(m1 - mt);
+            lsum = lsum * a0 + l1 * a1;
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * a0 + mine[(t * 16 + r) * 64] * a1;
+        }
+        __syncthreads();  // the merge image is consumed before the output staging overlays it
+    }
+    const float inv = 1.0f / lsum;
+    float* sO = reinterpret_cast<float*>(smem);  // [QB][OP]
+    if (kgrp == 0) {
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (dv < D) sO[(qw * 32 + l31) * OP + dv] = o[t][r] * inv;
+            }
+    }
     __syncthreads();
-    for (int e = tid; e < FA_QB * D4; e += 256) {
+    for (int e = tid; e < QB * D4; e += 256) {
         const int qlr = e / D4, c4 = e - qlr * D4;
         const int qi = q0 + qlr;
         if (qi >= nq) continue;
@@ -396,17 +433,19 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
     }
 }
 
-template <int KS, int DVT>
+template <int KS, int DVT, bool KSPLIT>
 static int launch_attn_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int batch, int heads,
                             int nq, int nk, float scale, float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld,
                             int out_rows, int out_row0, hipStream_t st) {
     constexpr int D = KS * 16;
+    constexpr int QB = KSPLIT ? FA_QB / 2 : FA_QB;
     constexpr size_t tiles = (size_t)(2 * FA_KB * (D + 8) + 2 * DVT * 32 * (FA_KB + 8)) * sizeof(wd_bf16);
-    constexpr size_t stage = (size_t)FA_QB * (D + 4) * sizeof(float);
-    constexpr size_t smem = tiles > stage ? tiles : stage;
+    constexpr size_t stage = (size_t)QB * (D + 4) * sizeof(float);
+    constexpr size_t merge = KSPLIT ? (size_t)2 * (DVT * 16 + 2) * 64 * sizeof(float) : 0;
+    constexpr size_t smem = (tiles > stage ? tiles : stage) > merge ? (tiles > stage ? tiles : stage) : merge;
     static_assert(smem <= 64 * 1024, "attention tile does not fit the default dynamic LDS limit");
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT>), dim3(heads, batch, (nq + FA_QB - 1) / FA_QB), dim3(256), smem, st, q, ldq, k,
+    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT, KSPLIT>), dim3(heads, batch, (nq + QB - 1) / QB), dim3(256), smem, st, q, ldq, k,
                        ldk, v, ldv, heads, nq, nk, scale, out_f32, out_hi, out_lo, out_ld, out_rows, out_row0);
     return wd_check_launch();
 }
@@ -451,9 +490,14 @@ extern "C" int wd_attention(const float* q, int ldq, const float* k, int ldk, co
     }
     if (nk > NKS && d % 16 == 0 && d <= 96 && out_ld % 4 == 0 && !getenv("WDIFF_ATTN_GENERIC")) {
         // spatial self-attention / long-context cross-attention: MFMA kernel (split-bf16, fp32 softmax)
-#define WD_FA(KS_, DVT_)                                                                                            \
-    return launch_attn_mfma<KS_, DVT_>(q, ldq, k, ldk, v, ldv, batch, heads, nq, nk, scale, out_f32, out_hi, out_lo, \
-                                       out_ld, out_rows, out_row0, st)
+        // 64-query tiles with the keys split over the wave pairs: maps of <= 64 positions (WDIFF_ATTN_KSPLIT=1 always, 0 never)
+        static const int ksplit_env = getenv("WDIFF_ATTN_KSPLIT") ? atoi(getenv("WDIFF_ATTN_KSPLIT")) : 2;
+        const bool ksplit = ksplit_env == 1 || (ksplit_env == 2 && nq <= 64);
+#define WD_FA(KS_, DVT_)                                                                                                          \
+    return ksplit ? launch_attn_mfma<KS_, DVT_, true>(q, ldq, k, ldk, v, ldv, batch, heads, nq, nk, scale, out_f32, out_hi, out_lo, \
+                                                      out_ld, out_rows, out_row0, st)                                               \
+                  : launch_attn_mfma<KS_, DVT_, false>(q, ldq, k, ldk, v, ldv, batch, heads, nq, nk, scale, out_f32, out_hi,        \
+                                                       out_lo, out_ld, out_rows, out_row0, st)
         switch (d / 16) {
             case 1: WD_FA(1, 1);
             case 2: WD_FA(2, 1);
