@@ -177,6 +177,18 @@ int wd_attention(const float* q, int ldq, const float* k, int ldk, const float* 
                  float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int out_rows, int out_row0,
                  void* stream);
 
+/* Attention over a context that stays fixed for many calls (the PHOSC cross-attention, unetPhosc.py:241-246 over 10 + 769
+ * tokens: the same K / V for all 999 steps of a sampling call).  wd_attention_pack_kv converts K / V [batch*nk][ld] (head h in
+ * columns [h*d, (h+1)*d)) ONCE into the split-bf16 key-block images the MFMA kernel keeps in LDS
+ * (wd_attention_packed_elems(...) bf16 elements, 16-byte aligned; 0 = shape not covered: nk <= 16 or d not in 16..96 step 16);
+ * wd_attention_packed is wd_attention reading those images.  Same arithmetic as wd_attention on the same K / V. */
+int64_t wd_attention_packed_elems(int batch, int heads, int nk, int d);
+int wd_attention_pack_kv(const float* k, int ldk, const float* v, int ldv, int batch, int heads, int nk, int d,
+                         wd_bf16* img, void* stream);
+int wd_attention_packed(const float* q, int ldq, const wd_bf16* img, int batch, int heads, int nq, int nk, int d,
+                        float scale, float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int out_rows,
+                        int out_row0, void* stream);
+
 /* timestep_embedding, unet.py:96-116: planes[b][0:half] = cos(t_b * freqs), [half:2*half] = sin(...).
  * freqs[half] is the fp32 table exp(-ln(1e4) k / half) computed by the caller with the reference's op order. */
 int wd_timestep_embedding(const int64_t* t, int batch, const float* freqs, int half,

@@ -814,3 +814,36 @@ def test_gemm_groupnorm_in_the_combine_launch(B, cin, cout, cpg, silu, film, res
     # not a K-cut launch -> error
     a1, _k1 = args_for(True, ksplit=1)
     assert lib.wd_gemm(C.byref(a1), _st()) != 0
+
+
+@pytest.mark.parametrize("B,H,nq,nk,d", [(3, 4, 256, 779, 80), (2, 4, 64, 779, 80), (2, 2, 100, 70, 32), (1, 1, 17, 130, 96)])
+def test_attention_over_prepacked_keys_and_values(B, H, nq, nk, d):
+    """wd_attention_pack_kv + wd_attention_packed (the K / V images of a fixed context built once) == wd_attention on the same
+    K / V: the same LDS images, the same products, the same bits - for 128-query tiles and for the key-split 64-query tiles."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(nq + nk + d)
+    inner = H * d
+    q = (torch.randn(B * nq, inner, generator=g)).to(DEV)
+    kv = (torch.randn(B * nk, 2 * inner + 8, generator=g)).to(DEV)
+    scale = d ** -0.5
+    nimg = lib.wd_attention_packed_elems(B, H, nk, d)
+    assert nimg > 0 and lib.wd_attention_packed_elems(B, H, 10, d) == 0
+    img = torch.empty(nimg, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.wd_attention_pack_kv(kv.data_ptr(), kv.shape[1], kv.data_ptr() + 4 * inner, kv.shape[1], B, H, nk, d, img.data_ptr(),
+                                     _st()), "pack")
+    ref = torch.full((B * nq, inner), float("nan"), device=DEV)
+    N.check(lib.wd_attention(q.data_ptr(), inner, kv.data_ptr(), kv.shape[1], kv.data_ptr() + 4 * inner, kv.shape[1], B, H, nq, nk, d,
+                             scale, ref.data_ptr(), None, None, inner, nq, 0, _st()), "attention")
+    out = torch.full((B * nq, inner), float("nan"), device=DEV)
+    pl = torch.zeros(2, B * nq, inner, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.wd_attention_packed(q.data_ptr(), inner, img.data_ptr(), B, H, nq, nk, d, scale, out.data_ptr(), pl[0].data_ptr(),
+                                    pl[1].data_ptr(), inner, nq, 0, _st()), "packed")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert max_rel(unplanes(pl).cpu(), ref.cpu()) < 1e-5
+    # and against fp64
+    qd, kd, vd = q.double().cpu(), kv[:, :inner].double().cpu(), kv[:, inner:2 * inner].double().cpu()
+    hd = lambda t, n: t.reshape(B, n, H, d).permute(0, 2, 1, 3)  # noqa: E731
+    att = torch.softmax(hd(qd, nq) @ hd(kd, nk).transpose(-1, -2) * scale, -1)
+    o = (att @ hd(vd, nk)).permute(0, 2, 1, 3).reshape(B * nq, inner)
+    assert max_rel(out.cpu(), o) < 2e-5

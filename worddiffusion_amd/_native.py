@@ -57,6 +57,9 @@ _SIGS = {
     "wd_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wd_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "wd_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "wd_attention_packed_elems": (C.c_int64, [_i, _i, _i, _i]),
+    "wd_attention_pack_kv": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wd_attention_packed": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "wd_timestep_embedding": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "wd_embed_tokens": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "wd_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -232,11 +232,47 @@ __device__ __forceinline__ void fa_split8(const float* f, fa_bf16x8& hi, fa_bf16
     lo = *reinterpret_cast<const fa_bf16x8*>(&lv);
 }
 
+// One block of FA_KB keys of one (sample, head): fp32 K / V rows -> split-bf16 LDS image (K planes by key, V^T planes with the keys
+// of each 32-block in the order the S^T accumulator delivers them).
+template <int D, int KP, int VP, int DVR>
+__device__ __forceinline__ void fa_convert_block(wd_bf16* sK, wd_bf16* sV, const float* __restrict__ k, int ldk,
+                                                 const float* __restrict__ v, int ldv, const int b, const int h, const int nk,
+                                                 const int kb, const int tid) {
+    constexpr int D4 = D / 4;
+    for (int e = tid; e < FA_KB * D4; e += 256) {
+        const int key = e / D4, c4 = e - key * D4;
+        const int gk = kb + key;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (gk < nk) {
+            kv = *reinterpret_cast<const float4*>(k + ((long)b * nk + gk) * ldk + h * D + c4 * 4);
+            vv = *reinterpret_cast<const float4*>(v + ((long)b * nk + gk) * ldv + h * D + c4 * 4);
+        }
+        uint2 hi, lo;
+        wd_split4(kv, hi, lo);
+        *reinterpret_cast<uint2*>(sK + (long)key * KP + c4 * 4) = hi;
+        *reinterpret_cast<uint2*>(sK + (long)(FA_KB + key) * KP + c4 * 4) = lo;
+        // V^T with the keys of each 32-block in accumulator order: position = key with bits 2 and 3 swapped
+        const int kl = key & 31;
+        const int pos = (key & 32) | (kl & 0x13) | ((kl & 4) << 1) | ((kl & 8) >> 1);
+        wd_split4(vv, hi, lo);
+        wd_bf16* vh = sV + (long)(c4 * 4) * VP + pos;
+        wd_bf16* vl = sV + (long)(DVR + c4 * 4) * VP + pos;
+        vh[0] = (wd_bf16)(hi.x & 0xffff); vh[VP] = (wd_bf16)(hi.x >> 16);
+        vh[2 * VP] = (wd_bf16)(hi.y & 0xffff); vh[3 * VP] = (wd_bf16)(hi.y >> 16);
+        vl[0] = (wd_bf16)(lo.x & 0xffff); vl[VP] = (wd_bf16)(lo.x >> 16);
+        vl[2 * VP] = (wd_bf16)(lo.y & 0xffff); vl[3 * VP] = (wd_bf16)(lo.y >> 16);
+    }
+}
+
 // KSPLIT: 64 queries per workgroup instead of 128 - the wave pairs {0, 1} and {2, 3} own the SAME 64 queries and take the even /
 // odd 32-key sub-blocks of every LDS block; their (max, sum, O) states are merged once at the end (the flash-decoding merge).  For
 // maps of <= 64 positions (4x16 level) the 128-query form left half of every MFMA tile empty and 256 workgroups to stream 779 keys
 // each: 74.6 us for a quarter of the work the 8x32 level does in 102.
-template <int KS, int DVT, bool KSPLIT>
+// PACKED: k points at the LDS images of the key blocks as wd_attention_pack_kv stored them ([sample][head][block][image], image =
+// exactly sK | sV below): a context that does not change over the 999 steps of a sampling call (the PHOSC cross-attention: 779
+// keys) is converted once, and a block is then 16-byte copies with the next block's in flight during this block's products -
+// instead of fp32 loads, the bf16 split and 2-byte transposing LDS writes in every workgroup of every step.
+template <int KS, int DVT, bool KSPLIT, bool PACKED = false>
 __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         int ldk, const float* __restrict__ v, int ldv, int heads, int nq,
                                                         int nk, float scale, float* __restrict__ out_f32,
@@ -281,7 +317,21 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
             fa_split8(f, qh[ks], ql[ks]);
         }
     }
-    if constexpr (DVR > D) {  // zero the dv padding rows of both planes once
+    constexpr int IMG = 2 * FA_KB * KP + 2 * DVR * VP;  // bf16 elements of one block's image
+    constexpr int NP16 = IMG / 8, NPF = PACKED ? (NP16 + 255) / 256 : 1;
+    static_assert(IMG % 8 == 0, "16-byte pieces");
+    const uint4* gimg = nullptr;
+    uint4 pre[NPF];
+    if constexpr (PACKED) {
+        const int nkb = (nk + FA_KB - 1) / FA_KB;
+        gimg = reinterpret_cast<const uint4*>(reinterpret_cast<const wd_bf16*>(k) + ((long)(b * heads + h) * nkb) * IMG);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + i * 256;
+            pre[i] = idx < NP16 ? gimg[idx] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if constexpr (DVR > D && !PACKED) {  // zero the dv padding rows of both planes once (the packed image carries its zeros)
         constexpr int PADN = (DVR - D) * VP;
         for (int e = tid; e < 2 * PADN; e += 256) {
             const int pl = e / PADN, r = e - pl * PADN;
@@ -297,28 +347,22 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
 
     for (int kb = 0; kb < nk; kb += FA_KB) {
         __syncthreads();  // the previous block has been consumed
-        for (int e = tid; e < FA_KB * D4; e += 256) {
-            const int key = e / D4, c4 = e - key * D4;
-            const int gk = kb + key;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (gk < nk) {
-                kv = *reinterpret_cast<const float4*>(k + ((long)b * nk + gk) * ldk + h * D + c4 * 4);
-                vv = *reinterpret_cast<const float4*>(v + ((long)b * nk + gk) * ldv + h * D + c4 * 4);
+        if constexpr (PACKED) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < NP16) reinterpret_cast<uint4*>(smem)[idx] = pre[i];
             }
-            uint2 hi, lo;
-            wd_split4(kv, hi, lo);
-            *reinterpret_cast<uint2*>(sK + (long)key * KP + c4 * 4) = hi;
-            *reinterpret_cast<uint2*>(sK + (long)(FA_KB + key) * KP + c4 * 4) = lo;
-            // V^T with the keys of each 32-block in accumulator order: position = key with bits 2 and 3 swapped
-            const int kl = key & 31;
-            const int pos = (key & 32) | (kl & 0x13) | ((kl & 4) << 1) | ((kl & 8) >> 1);
-            wd_split4(vv, hi, lo);
-            wd_bf16* vh = sV + (long)(c4 * 4) * VP + pos;
-            wd_bf16* vl = sV + (long)(DVR + c4 * 4) * VP + pos;
-            vh[0] = (wd_bf16)(hi.x & 0xffff); vh[VP] = (wd_bf16)(hi.x >> 16);
-            vh[2 * VP] = (wd_bf16)(hi.y & 0xffff); vh[3 * VP] = (wd_bf16)(hi.y >> 16);
-            vl[0] = (wd_bf16)(lo.x & 0xffff); vl[VP] = (wd_bf16)(lo.x >> 16);
-            vl[2 * VP] = (wd_bf16)(lo.y & 0xffff); vl[3 * VP] = (wd_bf16)(lo.y >> 16);
+            if (kb + FA_KB < nk) {  // the next block's image: in flight during this block's products
+                const uint4* nx = gimg + (long)(kb / FA_KB + 1) * NP16;
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < NP16) pre[i] = nx[idx];
+                }
+            }
+        } else {
+            fa_convert_block<D, KP, VP, DVR>(sK, sV, k, ldk, v, ldv, b, h, nk, kb, tid);
         }
         __syncthreads();
 #pragma unroll
@@ -433,7 +477,29 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
     }
 }
 
-template <int KS, int DVT, bool KSPLIT>
+template <int KS, int DVT>
+__global__ void __launch_bounds__(256) attn_pack_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                                                        int heads, int nk, wd_bf16* __restrict__ img) {
+    constexpr int D = KS * 16, KP = D + 8, VP = FA_KB + 8, DVR = DVT * 32;
+    constexpr int IMG = 2 * FA_KB * KP + 2 * DVR * VP, NP16 = IMG / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wd_bf16* sK = reinterpret_cast<wd_bf16*>(smem);
+    wd_bf16* sV = sK + 2 * FA_KB * KP;
+    const int kbi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    for (int i = tid; i < NP16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);  // every padding element
+    __syncthreads();
+    fa_convert_block<D, KP, VP, DVR>(sK, sV, k, ldk, v, ldv, b, h, nk, kbi * FA_KB, tid);
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(img + ((long)(b * heads + h) * gridDim.x + kbi) * IMG);
+    for (int i = tid; i < NP16; i += 256) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
+}
+
+template <int KS, int DVT>
+static constexpr long fa_image_elems() {
+    return 2L * FA_KB * (KS * 16 + 8) + 2L * DVT * 32 * (FA_KB + 8);
+}
+
+template <int KS, int DVT, bool KSPLIT, bool PACKED = false>
 static int launch_attn_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int batch, int heads,
                             int nq, int nk, float scale, float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld,
                             int out_rows, int out_row0, hipStream_t st) {
@@ -445,7 +511,7 @@ static int launch_attn_mfma(const float* q, int ldq, const float* k, int ldk, co
     constexpr size_t smem = (tiles > stage ? tiles : stage) > merge ? (tiles > stage ? tiles : stage) : merge;
     static_assert(smem <= 64 * 1024, "attention tile does not fit the default dynamic LDS limit");
     WdLaunchScope scope(WD_CLS_ATTN, st);
-    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT, KSPLIT>), dim3(heads, batch, (nq + QB - 1) / QB), dim3(256), smem, st, q, ldq, k,
+    hipLaunchKernelGGL((attn_mfma_kernel<KS, DVT, KSPLIT, PACKED>), dim3(heads, batch, (nq + QB - 1) / QB), dim3(256), smem, st, q, ldq, k,
                        ldk, v, ldv, heads, nq, nk, scale, out_f32, out_hi, out_lo, out_ld, out_rows, out_row0);
     return wd_check_launch();
 }
@@ -520,3 +586,61 @@ extern "C" int wd_attention(const float* q, int ldq, const float* k, int ldk, co
                        ldv, heads, nq, nk, d, scale, out_f32, out_hi, out_lo, out_ld, out_rows, out_row0);
     return wd_check_launch();
 }
+
+// ---- key / value images for a context that stays fixed over a sampling call (see attn_mfma_kernel PACKED)
+#define WD_FA_CASES(X) \
+    switch (d / 16) {  \
+        case 1: X(1, 1); \
+        case 2: X(2, 1); \
+        case 3: X(3, 2); \
+        case 4: X(4, 2); \
+        case 5: X(5, 3); \
+        case 6: X(6, 3); \
+    }
+
+extern "C" int64_t wd_attention_packed_elems(int batch, int heads, int nk, int d) {
+    if (batch <= 0 || heads <= 0 || nk <= NKS || d <= 0 || d % 16 || d > 96) return 0;
+    const long nkb = (nk + FA_KB - 1) / FA_KB;
+#define WD_X(KS_, DVT_) return (int64_t)batch * heads * nkb * fa_image_elems<KS_, DVT_>()
+    WD_FA_CASES(WD_X)
+#undef WD_X
+    return 0;
+}
+
+extern "C" int wd_attention_pack_kv(const float* k, int ldk, const float* v, int ldv, int batch, int heads, int nk, int d,
+                                    wd_bf16* img, void* stream) {
+    if (!k || !v || !img || ldk % 4 || ldv % 4 || wd_attention_packed_elems(batch, heads, nk, d) == 0) return WD_EINVAL;
+    if (reinterpret_cast<uintptr_t>(img) & 15) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nkb = (nk + FA_KB - 1) / FA_KB;
+    WdLaunchScope scope(WD_CLS_ATTN, st);
+#define WD_X(KS_, DVT_)                                                                                                    \
+    {                                                                                                                      \
+        hipLaunchKernelGGL((attn_pack_kernel<KS_, DVT_>), dim3(nkb, heads, batch), dim3(256),                               \
+                           ((size_t)fa_image_elems<KS_, DVT_>() * sizeof(wd_bf16)), st, k, ldk, v, ldv, heads, nk, img);    \
+        return wd_check_launch();                                                                                          \
+    }
+    WD_FA_CASES(WD_X)
+#undef WD_X
+    return WD_EINVAL;
+}
+
+extern "C" int wd_attention_packed(const float* q, int ldq, const wd_bf16* img, int batch, int heads, int nq, int nk, int d,
+                                   float scale, float* out_f32, wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, int out_rows,
+                                   int out_row0, void* stream) {
+    if (!q || !img || (!out_f32 && !out_hi) || nq <= 0 || ldq % 4 || out_ld % 4) return WD_EINVAL;
+    if (wd_attention_packed_elems(batch, heads, nk, d) == 0 || (reinterpret_cast<uintptr_t>(img) & 15)) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float* kimg = reinterpret_cast<const float*>(img);
+    static const int ksplit_env = getenv("WDIFF_ATTN_KSPLIT") ? atoi(getenv("WDIFF_ATTN_KSPLIT")) : 2;
+    const bool ksplit = ksplit_env == 1 || (ksplit_env == 2 && nq <= 64);
+#define WD_X(KS_, DVT_)                                                                                                            \
+    return ksplit ? launch_attn_mfma<KS_, DVT_, true, true>(q, ldq, kimg, 0, nullptr, 0, batch, heads, nq, nk, scale, out_f32,       \
+                                                            out_hi, out_lo, out_ld, out_rows, out_row0, st)                          \
+                  : launch_attn_mfma<KS_, DVT_, false, true>(q, ldq, kimg, 0, nullptr, 0, batch, heads, nq, nk, scale, out_f32,      \
+                                                             out_hi, out_lo, out_ld, out_rows, out_row0, st)
+    WD_FA_CASES(WD_X)
+#undef WD_X
+    return WD_EINVAL;
+}
+#undef WD_FA_CASES

@@ -291,6 +291,7 @@ class UNetEngine:
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
+        self.pack_kv = os.environ.get("WDIFF_PACK_KV", "1") != "0"         # long-context cross-attention: K/V images built once per call
         self.fuse_gn2 = os.environ.get("WDIFF_FUSE_GN2", "1") != "0"       # GroupNorm over [h | skip]: one apply launch for both
         self.fuse_gn = os.environ.get("WDIFF_FUSE_GN", "1") != "0"         # GroupNorm in the producer's split-K combine launch
         self.fuse_split = os.environ.get("WDIFF_FUSE_SPLIT", "1") != "0"   # resample inputs: planes from the producer's epilogue
@@ -847,8 +848,21 @@ class UNetEngine:
                 self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
                 ko = self.kv_off[p + ".a2"]
                 o2 = self._planes(P, M, inner)
-                self._attention(ops, p + ".a2", q2.data_ptr(), inner, self._kv.data_ptr() + 4 * ko, self.kv_total,
-                                self._kv.data_ptr() + 4 * (ko + inner), self.kv_total, heads, hw, L, d, scale, o2)
+                kp, vp = self._kv.data_ptr() + 4 * ko, self._kv.data_ptr() + 4 * (ko + inner)
+                nimg = self.lib.wd_attention_packed_elems(B, heads, L, d) if self.pack_kv else 0
+                if nimg > 0:
+                    # the context's keys / values do not change during a sampling call: their split-bf16 LDS images are built
+                    # once per call (P.cond, after the K/V projection) and every step's attention copies them 16 bytes at a time
+                    img = torch.empty(nimg, dtype=torch.bfloat16, device=self.device)
+                    P.keep.append(img)
+                    P.cond.append((self.lib.wd_attention_pack_kv,
+                                   (kp, self.kv_total, vp, self.kv_total, B, heads, L, d, img.data_ptr()), p + ".a2:pack kv"))
+                    ops.append((self.lib.wd_attention_packed,
+                                (q2.data_ptr(), inner, img.data_ptr(), B, heads, hw, L, d, float(scale), None, o2[0].data_ptr(),
+                                 o2[1].data_ptr() if self.npass == 3 else None, inner, hw, 0), p + ".a2"))
+                else:
+                    self._attention(ops, p + ".a2", q2.data_ptr(), inner, kp, self.kv_total, vp, self.kv_total, heads, hw, L, d,
+                                    scale, o2)
                 self._gemm(ops, p + ".a2.out", [self._src(o2, inner)], p + ".a2.o.w", M, hw, bias=self._w[p + ".a2.o.b"],
                            resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner)
             # ---- GEGLU feed-forward
