@@ -13,7 +13,9 @@ Philox streams keyed by the global sample index.
 
 Prints ONE JSON line on rank 0 with the driver's fields plus
   roofline     - the dominant kernel class (tap-gather MFMA GEMM): algorithmic FLOP / hipEvent-measured time;
-  cpu_baseline - the CPU oracle (a port: the reference itself does not travel) on this box's host cores.
+  cpu_baseline - the CPU oracle (a port: the reference itself does not travel) on this box's host cores;
+and, at N = 1, extras that never cost the line: full_call (one real Diffusion.sampling() of 64 words x 999 steps), train_step
+(BASELINE configs[2]: the train.py loop, + one epoch over cached latents), phosc_variant (configs[4] on one GPU), vae_decode.
 """
 from __future__ import annotations
 
@@ -444,6 +446,7 @@ def main():
                          "multi-GPU run is the scaling measurement of the headline metric, pass a count to add the data-parallel "
                          "training leg with its gradient all-reduce)")
     ap.add_argument("--no-full-call", action="store_true", help="skip the un-extrapolated full sampling() call")
+    ap.add_argument("--no-phosc", action="store_true", help="skip the PHOSC-variant extra (BASELINE configs[4] on one GPU)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous / barrier / max-over-ranks only, no GPU work (CPU rehearsal of the N-rank control flow)")
     a = ap.parse_args()
@@ -536,6 +539,29 @@ def main():
         prof_extra = {N.CLASS_NAMES[i]: dict(ms_per_step=ms[i] / nprof, launches_per_step=int(cnt[i]) // nprof)
                       for i in range(N.NCLASS)}
 
+    phosc_extra = None
+    if rank == 0 and world == 1 and a.variant == "base" and not a.no_phosc:
+        # BASELINE configs[4] (PHOSC-conditioned sampling; sharded over the ranks like the headline, no collective): one GPU's share -
+        # the same loop with UNetModelPhosc and the 769-int PHOSC vector (self-attention + 779-key cross-attention per block)
+        try:
+            pm, pargs = build_model(dev, a.precision, "phosc")
+            pr = StepRunner(pm, pargs, dev, B, seed=4321, sample_offset=0, phosc_len=769)
+            pr.capture()
+            pr.run(10)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pr.run(200)
+            torch.cuda.synchronize()
+            pms = 1e3 * (time.perf_counter() - t0) / 200
+            phosc_extra = dict(workload="configs[4] on one GPU: UNetModelPhosc (args.phosc = 1), batch %d, 10 text + 769 PHOSC tokens, "
+                                        "200 graph-replayed steps" % B, ms_per_step=pms,
+                               images_per_sec=B * 1e3 / (pms * (T - 1)), per_call_setup_ms=pr.setup_ms,
+                               output_finite=bool(torch.isfinite(pr.P.x_in).all().item()))
+            del pr, pm
+            torch.cuda.empty_cache()
+        except Exception as e:  # an extra: never costs the headline line
+            phosc_extra = dict(error=f"{type(e).__name__}: {e}")
+
     full_call = None
     if not a.no_full_call and a.variant == "base" and B == BATCH:
         try:
@@ -585,7 +611,7 @@ def main():
                                 images_per_sec_per_gpu=value / world, output_finite=finite,
                                 per_call_setup_ms=setup_ms, kernel_sources_sha256=_lib_digest()),
                     roofline=roof, cpu_baseline=cpu, full_call=full_call, kernel_classes=prof_extra, train_step=train,
-                    vae_decode=vae)
+                    vae_decode=vae, phosc_variant=phosc_extra)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

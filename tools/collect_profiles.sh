@@ -10,12 +10,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/${TAG}_bench_full.json 2> $OUT/${TAG}_bench_full.err || exit 1
 echo "[collect] bench done"
-B="$ROOT/bench.py --no-cpu-baseline --train-steps 0 --no-vae --no-full-call"
+B="$ROOT/bench.py --no-cpu-baseline --train-steps 0 --no-vae --no-full-call --no-phosc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bench -o b -- python3 $B > $OUT/${TAG}_prof_bench.log 2>&1 || exit 2
 echo "[collect] bench kernel stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o t -- python3 $ROOT/tools/train_prof.py > $OUT/${TAG}_prof_train.log 2>&1 || exit 3
 echo "[collect] train kernel stats done"
-P="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call"
+P="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call --no-phosc"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $P > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 4
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 $P > $OUT/${TAG}_pmc_write.log 2>&1 || exit 5
 F=$(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
