@@ -77,12 +77,14 @@ typedef struct wd_gemm_args {
     wd_bf16* out_hi;      /* split-bf16 planes of the result for the next GEMM, or NULL */
     wd_bf16* out_lo;
     int32_t out_pl_ld;
-    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128128, 128160, 64064) */
+    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128128, 128160, 64064; 64320 with w_layout 3) */
     int32_t w_layout;     /* 0: w = [n][ktot].  1: "slab order" [stage][n][32], stage = (32-channel chunk, tap) of src0
                            * (chunk-major, tap-minor) followed by the 32-channel chunks of src1: selects the kernel that
-                           * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2) */
+                           * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2)
+                           * 3: fragment-major weights (wd_gemm_pack_w), 64 x 320 tiles, weights loaded straight into registers;
+                           *    statistics (stat_part) are then kept per 64-row chunk: nchunk = max(1, hw_out / 64) */
     int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192
-                           * w_layout 2: w = [n][ktot] as for 0, src[0] is a 3x3 / pad 1 / stride 1 convolution (9 taps, its usual
+                           * w_layout 2 or 3: w as for 0 (2) / fragment-major (3), src[0] is a 3x3 / pad 1 / stride 1 convolution (9 taps, its usual
                            * gather table) over images of width slab_rows, src[1] (optional) an identity source: selects the
                            * kernel that loads the A tile of a kernel row once for its three taps when WDIFF_CONV3=1; in every case
                            * it lets the kernel compute the source rows of a panel instead of reading the gather table */
@@ -118,6 +120,13 @@ typedef struct wd_gemm_args {
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);
+
+/* wd_gemm_args.w_layout == 3: the weights of a GEMM with n % 320 == 0, ktot % 64 == 0 in FRAGMENT-MAJOR order - the 16 bytes
+ * lane l of a v_mfma_f32_16x16x32_bf16 B fragment holds, W[16 ct + (l & 15)][32 ks + 8 (l >> 4) .. + 8], at byte
+ * ((ks * n/16 + ct) * 64 + l) * 16 of the plane - so a wave loads a fragment as one contiguous kilobyte straight into
+ * registers and the weights never pass through LDS (64 x 320 tiles, csrc/wd_gemmw.hip; same nn.Conv2d / nn.Linear layers as
+ * wd_gemm: unet.py:595,621,632,540,488,364,375,145).  wd_gemm_pack_w converts [n][ktot] planes (lo / out_lo may be NULL). */
+int wd_gemm_pack_w(const wd_bf16* hi, const wd_bf16* lo, int n, int ktot, wd_bf16* out_hi, wd_bf16* out_lo, void* stream);
 
 /* The number of K slices wd_gemm picks by itself (ksplit = 0, tile = 0) for an m x n x ktot product with a workspace of
  * ws_floats floats and no GEGLU: 1 = no cut.  (What a caller needs to know before it asks for the GroupNorm epilogue.) */

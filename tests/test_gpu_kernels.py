@@ -38,7 +38,8 @@ SLAB = [False, True]
 
 
 def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, resid_rows=None, act=0,
-             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0, dbg=0, tickets=None):
+             want_f32=True, want_planes=False, tile=0, n=None, slab=False, ksplit=1, same_w=0, dbg=0, tickets=None, wdirect=False,
+             stat_part=None, stat_cpg=0):
     """a_list: list of (planes[2,rows,ld], c, ntaps, gather(int32 tensor|None), hw_src).
     slab=True: weights in slab order + the LDS-resident-slab kernel (w_layout 1)."""
     lib = N.lib()
@@ -59,8 +60,16 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
             pytest.skip("slab kernel not applicable (span / tile)")
         wp = slab_order(wp, a_list[0][2], a_list[0][1], a_list[1][1] if len(a_list) > 1 else 0)
         args.w_layout, args.slab_rows = 1, span
-    if same_w:  # row-shared taps kernel for 3x3 / pad 1 / stride 1 (w_layout 2)
+    if same_w and not wdirect:  # row-shared taps kernel for 3x3 / pad 1 / stride 1 (w_layout 2)
         args.w_layout, args.slab_rows = 2, same_w
+    if wdirect:  # fragment-major weights, loaded straight into the MFMA operand registers (w_layout 3; tile 64320 or 128160)
+        wf = torch.empty_like(wp)
+        N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), wp.shape[1], wp.shape[2], wf[0].data_ptr(), wf[1].data_ptr(),
+                                   _st()), "wd_gemm_pack_w")
+        wp = wf
+        args.w_layout, args.slab_rows = 3, same_w
+    if stat_part is not None:
+        args.stat_part, args.stat_cpg = stat_part.data_ptr(), stat_cpg
     keep.append(wp)
     args.w_hi, args.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
     n = w.shape[0] if n is None else n
@@ -243,6 +252,64 @@ def test_gemm_two_workgroups_per_cu_kernel(B, hh, ww, c1, c2, n, ksplit):
     assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(unplanes(pl).cpu(), ref) < 2e-5
     out0, _ = run_gemm(srcs, wcat.to(DEV), m, hw, **kw)
     assert max_rel(out.cpu(), out0.cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("B,hh,ww,c1,c2,n,ksplit,npass,tile", [
+    (4, 4, 16, 320, 640, 320, 1, 3, 64320), (4, 4, 16, 320, 640, 320, 3, 3, 64320), (3, 8, 32, 64, 0, 320, 1, 3, 64320),
+    (5, 5, 7, 128, 64, 320, 1, 3, 64320), (5, 5, 7, 128, 64, 320, 2, 1, 64320), (64, 8, 32, 64, 0, 320, 1, 3, 64320),
+    (2, 8, 32, 64, 0, 640, 1, 3, 64320), (4, 4, 16, 320, 640, 320, 1, 3, 128160), (5, 5, 7, 128, 64, 160, 2, 3, 128160),
+    (3, 8, 32, 64, 64, 480, 1, 1, 128160), (2, 8, 32, 320, 0, 320, 0, 3, 64320)])
+def test_gemm_weights_to_registers_kernel(B, hh, ww, c1, c2, n, ksplit, npass, tile):
+    """wd_gemmw_kernel (w_layout 3: fragment-major weights from wd_gemm_pack_w, loaded straight into the MFMA operand registers;
+    64 x 320 and 128 x 160 tiles): 3x3 gather source (gather table and the computed table) + optional identity skip source, FiLM
+    row vector, residual, planes out, ragged M, odd and even stage counts, split-K, single-pass bf16 - vs fp64 and vs the
+    LDS-staged kernel (same K-half split and order: the same bits without a K cut); repeated launches give the same bits."""
+    g = torch.Generator().manual_seed(B + hh + ww + c1 + n + tile)
+    hw, m = hh * ww, B * hh * ww
+    a1 = torch.randn(m, c1, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    wcat = torch.randn(n, 9 * c1 + c2, generator=g) / (9 * c1 + c2) ** 0.5
+    bias, film, res = torch.randn(n, generator=g), torch.randn(B, n, generator=g), torch.randn(m, n, generator=g)
+    x1 = a1.reshape(B, hh, ww, c1).permute(0, 3, 1, 2)
+    ref = (F.conv2d(x1.double(), wcat[:, :9 * c1].reshape(n, 3, 3, c1).permute(0, 3, 1, 2).double(), padding=1)
+           .permute(0, 2, 3, 1).reshape(m, n) + bias.double() + film.double().repeat_interleave(hw, 0) + res.double())
+    srcs = [(planes_of(a1.to(DEV)), c1, 9, torch.from_numpy(tab).to(DEV), hw)]
+    if c2:
+        a2 = torch.randn(m, c2, generator=g)
+        ref = ref + a2.double() @ wcat[:, 9 * c1:].double().t()
+        srcs.append((planes_of(a2.to(DEV)), c2, 1, None, 0))
+    kw = dict(bias=bias.to(DEV), rowvec=film.to(DEV), resid=res.to(DEV), want_planes=True, ksplit=ksplit, npass=npass)
+    tol = 2e-5 if npass == 3 else 2e-2
+    for same_w in (0, ww):
+        out, pl = run_gemm(srcs, wcat.to(DEV), m, hw, wdirect=True, tile=tile, same_w=same_w, **kw)
+        assert rel_err(out.cpu(), ref) < tol and rel_err(unplanes(pl).cpu(), ref) < (tol if npass == 3 else 3e-2)
+        out2, _ = run_gemm(srcs, wcat.to(DEV), m, hw, wdirect=True, tile=tile, same_w=same_w, **kw)
+        assert torch.equal(out, out2)
+    out0, _ = run_gemm(srcs, wcat.to(DEV), m, hw, tile=128160 if n % 160 == 0 else 0, **kw)
+    assert max_rel(out.cpu(), out0.cpu()) < (5e-6 if npass == 3 else 1e-2)
+
+
+@pytest.mark.parametrize("B,hh,ww,cin,n,tile,ksplit", [(3, 8, 32, 64, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 0),
+                                                        (3, 8, 32, 64, 320, 128160, 1), (5, 8, 8, 64, 640, 64320, 1)])
+def test_gemm_weights_to_registers_kernel_statistics(B, hh, ww, cin, n, tile, ksplit):
+    """Fused GroupNorm statistics of the weights-to-registers kernel: kept per row panel of the tile (nchunk = hw / 64 for the 64-row
+    tile), equal to sums over the finished output."""
+    g = torch.Generator().manual_seed(n + hh + tile)
+    hw, m = hh * ww, B * hh * ww
+    a = torch.randn(m, cin, generator=g)
+    w = torch.randn(n, 9 * cin, generator=g) / (9 * cin) ** 0.5
+    bias, film = torch.randn(n, generator=g), torch.randn(B, n, generator=g)
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    cpg = n // 32
+    nchunk = max(1, hw // (tile // 1000))
+    part = torch.full((B, nchunk, 32, 2), float("nan"), dtype=torch.float64, device=DEV)
+    srcs = [(planes_of(a.to(DEV)), cin, 9, torch.from_numpy(tab).to(DEV), hw)]
+    out, _ = run_gemm(srcs, w.to(DEV), m, hw, wdirect=True, tile=tile, bias=bias.to(DEV), rowvec=film.to(DEV), ksplit=ksplit,
+                      stat_part=part, stat_cpg=cpg)
+    o = out.cpu().double().reshape(B, hw, 32, cpg)
+    got = part.cpu().sum(dim=1)
+    assert torch.isfinite(got).all()
+    assert max_rel(got[..., 0], o.sum(dim=(1, 3))) < 1e-5 and max_rel(got[..., 1], (o * o).sum(dim=(1, 3))) < 1e-5
 
 
 @pytest.mark.parametrize("B,hh,ww,c1,c2,n,ksplit,npass", [(4, 4, 16, 320, 640, 320, 1, 3), (3, 8, 32, 64, 0, 160, 1, 3), (5, 5, 7, 128, 64, 200, 1, 3),

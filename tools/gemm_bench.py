@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="batch size (default: the module's B)")
     ap.add_argument("--conv3", type=int, default=0, help="1: row-shared-taps kernel for the 3x3 shapes (w_layout 2)")
     ap.add_argument("--stamps", type=int, default=0, help="1: per-stage cycle stamps of workgroup 0 (s_memtime)")
+    ap.add_argument("--wdirect", type=int, default=0, help="1: fragment-major weights, 64 x 320 weights-to-registers kernel (w_layout 3); "
+                    "the result is compared with the default kernel's first")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
                     "2: same, then read the weights once (emulates a prefetch) before the launch")
     a = ap.parse_args()
@@ -92,8 +94,21 @@ def main():
         if a.conv3 and kind == "conv3":
             g.w_layout, g.slab_rows = 2, w
             g.dbg = a.dbg | 0x1000
+        if a.wdirect and cout % 160 == 0 and kind != "geglu":
+            N.check(lib.wd_gemm(C.byref(g), st), name)   # reference result from the default kernel
+            ref = out.clone()
+            wf = torch.empty_like(wt)
+            N.check(lib.wd_gemm_pack_w(wt[0].data_ptr(), wt[1].data_ptr(), cout, ktot, wf[0].data_ptr(), wf[1].data_ptr(), st), "pack_w")
+            g.w_hi, g.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
+            g.w_layout, g.slab_rows, g.tile = 3, (w if ntaps == 9 else 0), (64320 if a.wdirect == 2 else 128160)
+            if a.ksplit != 1:
+                g.ksplit = a.ksplit
+            out.zero_()
+            N.check(lib.wd_gemm(C.byref(g), st), name + " (w-direct)")
+            torch.cuda.synchronize()
+            print(f"{name}: w-direct vs default kernel max |diff| {float((out - ref).abs().max()):.3e}  (max |ref| {float(ref.abs().max()):.3f})", flush=True)
         if a.stamps:
-            nk = ktot // 64
+            nk = (ktot // 64 + 1) & ~1 if a.wdirect else ktot // 64
             sb = torch.zeros(8 * nk * 4, dtype=torch.int64, device=DEV)
             g.ws, g.ws_floats, g.dbg = sb.data_ptr(), 0, a.dbg | 0x100
             N.check(lib.wd_gemm(C.byref(g), st), name)
@@ -112,7 +127,7 @@ def main():
                 print(f"{name} wave {wv}: per stage (s_memtime ticks, 100 MHz?) wait {wait[2:-1].mean():.1f}  frag-read {rd[2:-1].mean():.1f}  "
                       f"mfma+dma {mf[2:-1].mean():.1f}  stage {tot[2:-1].mean():.1f}   whole loop {int(w[-1, 3] - w[0, 0])}")
             g.dbg = a.dbg
-            g.ws, g.ws_floats = None, 0
+            g.ws, g.ws_floats = (ws.data_ptr(), ws.numel()) if a.ksplit != 1 else (None, 0)
         if a.slab:
             g.w_layout, g.slab_rows = 1, slab_span(tab_np, hw, hw, m)
         if kind == "geglu" and not g.tile:

@@ -45,6 +45,7 @@ class WdGemmArgs(C.Structure):
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
     "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
+    "wd_gemm_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "wd_gemm_args_bytes": (_i, []),
     "wd_gn_nchunk": (_i, [_i]),
     "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -284,6 +284,10 @@ class UNetEngine:
         self._w: Dict[str, torch.Tensor] = {}
         self._w3: Dict[str, torch.Tensor] = {}      # slab-order copies of the matrices the v3 kernel consumes
         self._w3_meta: Dict[str, tuple] = {}
+        self._wf: Dict[str, torch.Tensor] = {}      # fragment-major copies of the matrices the weights-to-registers kernel reads
+        # 64 x 320 tiles with the weights loaded straight into the MFMA operand registers (csrc/wd_gemmw.hip): the 320-column
+        # layers whose grid fills the chip without a K cut
+        self.use_wdirect = os.environ.get("WDIFF_GEMM_WDIRECT", "1") != "0"
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
@@ -452,6 +456,7 @@ class UNetEngine:
         if self.device is not None and dev != self.device:
             self._w.clear()
             self._w3.clear()
+            self._wf.clear()
             self._w3_meta.clear()
             self._plans.clear()
             self._tabs.clear()
@@ -473,6 +478,8 @@ class UNetEngine:
         _, table, chunks, n = self._pack
         stream = torch.cuda.current_stream(dev).cuda_stream
         N.check(self.lib.wd_repack_multi(table.data_ptr(), n, chunks, stream), "wd_repack_multi")
+        for name, wf in self._wf.items():
+            self._pack_wf(name, wf, stream)
         with torch.no_grad():
             for name, meta in self._w3_meta.items():
                 self._w3[name].copy_(slab_order(self._w[name], *meta))
@@ -482,6 +489,11 @@ class UNetEngine:
                 self._w["freqs"] = freqs.to(dev)
                 self._w["pe"] = self.model.word_emb.positional_encoding.to(dev).contiguous()
         self._sig = sig
+
+    def _pack_wf(self, name, wf, stream):
+        wp = self._w[name]
+        N.check(self.lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), wp.shape[1], wp.shape[2], wf[0].data_ptr(),
+                                        wf[1].data_ptr(), stream), "wd_gemm_pack_w")
 
     # ------------------------------------------------------------------------------------------ helpers
     def _table(self, h, w, mode):
@@ -536,7 +548,19 @@ class UNetEngine:
             # the slab kernel runs 128-row panels: only worth it when they fill the chip
             if span > 192 or ((m + 127) // 128) * max(1, nrows // 160) < 96:
                 span = 0
-        if span:
+        wdirect = (self.use_wdirect and not span and not self.use_conv3 and w_row_off == 0 and n is None and act == N.ACT_NONE and
+                   tile == 0 and nrows % 320 == 0 and ktot % 64 == 0 and all(s.c % 64 == 0 for s in srcs) and srcs[0].ntaps <= 9 and
+                   (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather)) and
+                   ((m + 63) // 64) * (nrows // 320) >= 256)
+        if wdirect:
+            if wname not in self._wf:
+                self._wf[wname] = torch.empty_like(wp)
+                self._pack_wf(wname, self._wf[wname], torch.cuda.current_stream(self.device).cuda_stream)
+            wf = self._wf[wname]
+            a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
+            a.w_layout, a.slab_rows = 3, getattr(srcs[0], "_same_w", 0) if srcs[0].ntaps == 9 else 0
+            tile = 64320
+        elif span:
             meta = (srcs[0].ntaps, srcs[0].c, srcs[1].c if len(srcs) > 1 else 0)
             if wname not in self._w3:
                 self._w3[wname] = slab_order(wp, *meta)
@@ -567,8 +591,8 @@ class UNetEngine:
         if want_stats and self.fuse_stats and nrows % 32 == 0 and (hw_out % 128 == 0 or hw_out == 64):
             cpg = nrows // 32
             bn = (tile % 1000) if tile else (160 if nrows % 160 == 0 else 64)
-            if bn % cpg == 0 and (tile == 0 or tile // 1000 == 128) and not span:
-                nchunk = max(1, hw_out // 128)
+            if bn % cpg == 0 and (tile == 0 or tile // 1000 == 128 or wdirect) and not span:
+                nchunk = max(1, hw_out // (64 if wdirect else 128))  # (the statistics are kept per row panel of the tile)
                 part = torch.zeros((m // hw_out, nchunk, 32, 2), dtype=torch.float64, device=self.device)
                 self._cur_plan.keep.append(part)
                 a.stat_part, a.stat_cpg = part.data_ptr(), cpg
