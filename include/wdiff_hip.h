@@ -128,6 +128,46 @@ int wd_gemm(const wd_gemm_args* args, void* stream);
  * wd_gemm: unet.py:595,621,632,540,488,364,375,145).  wd_gemm_pack_w converts [n][ktot] planes (lo / out_lo may be NULL). */
 int wd_gemm_pack_w(const wd_bf16* hi, const wd_bf16* lo, int n, int ktot, wd_bf16* out_hi, wd_bf16* out_lo, void* stream);
 
+/* The GEGLU feed-forward of a transformer block with its residual in one launch per 64-token panel (csrc/wd_ff.hip):
+ *     out = resid + GEGLU(x W1^T + b1) W2^T + b2        FeedForward / GEGLU unet.py:122-149, residual unet.py:343-344
+ * x: split-bf16 planes of LayerNorm(norm3) of the tokens, [m][x_ld]; c = 320 channels, inner hidden units (a multiple of 128).
+ * w1: wd_gemm_pack_w image of the [2 * inner][c] projection with its rows reordered in blocks of 16 x-rows followed by their 16
+ * gate rows (unet.py:128 chunk(2): x = rows [0, inner), gate = rows [inner, 2 inner)); b1 in the same order.  w2: wd_gemm_pack_w
+ * image of the [c][inner] output projection.  The hidden activations never leave the chip.  The result goes through the GEMM
+ * epilogue: fp32 out_f32 and / or split-bf16 planes out_hi / out_lo, optional GroupNorm statistics (stat_part per 64-row panel:
+ * nchunk = max(1, hw_out / 64), as wd_gemm with 64-row tiles).  w3 / b3 / resid3: reserved (must be NULL). */
+typedef struct wd_ff_args {
+    const wd_bf16* x_hi;
+    const wd_bf16* x_lo;
+    int32_t x_ld;
+    int32_t m, c, inner;
+    const wd_bf16* w1_hi;
+    const wd_bf16* w1_lo;
+    const float* b1;
+    const wd_bf16* w2_hi;
+    const wd_bf16* w2_lo;
+    const float* b2;
+    const float* resid; /* [m][resid_ld] or NULL */
+    int32_t resid_ld;
+    float* out_f32;
+    int32_t out_ld;
+    wd_bf16* out_hi;
+    wd_bf16* out_lo;
+    int32_t out_pl_ld;
+    const wd_bf16* w3_hi;
+    const wd_bf16* w3_lo;
+    const float* b3;
+    const float* resid3;
+    int32_t resid3_ld;
+    double* stat_part;
+    int32_t stat_cpg;
+    int32_t hw_out;
+    int32_t npass;
+} wd_ff_args;
+int wd_ff_fused(const wd_ff_args* args, void* stream);
+int wd_ff_supported(int c, int inner); /* 1 when wd_ff_fused covers the shape */
+int wd_ff_args_bytes(void);
+
 /* The number of K slices wd_gemm picks by itself (ksplit = 0, tile = 0) for an m x n x ktot product with a workspace of
  * ws_floats floats and no GEGLU: 1 = no cut.  (What a caller needs to know before it asks for the GroupNorm epilogue.) */
 int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats);

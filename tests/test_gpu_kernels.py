@@ -289,6 +289,59 @@ def test_gemm_weights_to_registers_kernel(B, hh, ww, c1, c2, n, ksplit, npass, t
     assert max_rel(out.cpu(), out0.cpu()) < (5e-6 if npass == 3 else 1e-2)
 
 
+@pytest.mark.parametrize("m,inner,npass,planes", [(64, 1280, 3, True), (200, 1280, 3, False), (4096, 1280, 3, True), (130, 256, 1, True)])
+def test_fused_geglu_feed_forward(m, inner, npass, planes):
+    """wd_ff_fused: x + GEGLU(LN(x) W1^T + b1) W2^T + b2 (unet.py:122-149, 343-344) in one launch - hidden activations never
+    stored - vs fp64, at ragged token counts, as fp32 and as split-bf16 planes; repeated launches give the same bits."""
+    lib = N.lib()
+    c = 320
+    assert lib.wd_ff_supported(c, inner)
+    g = torch.Generator().manual_seed(m + inner)
+    x = torch.randn(m, c, generator=g)
+    w1 = torch.randn(2 * inner, c, generator=g) / c ** 0.5
+    b1 = torch.randn(2 * inner, generator=g)
+    w2 = torch.randn(c, inner, generator=g) / inner ** 0.5
+    b2, res = torch.randn(c, generator=g), torch.randn(m, c, generator=g)
+    xd, w1d, w2d = x.double(), w1.double(), w2.double()
+    hid = (xd @ w1d[:inner].t() + b1[:inner].double()) * F.gelu(xd @ w1d[inner:].t() + b1[inner:].double())
+    ref = res.double() + hid @ w2d.t() + b2.double()
+
+    def pack(w):
+        wp = planes_of(w.to(DEV))
+        wf = torch.empty_like(wp)
+        N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), wp.shape[1], wp.shape[2], wf[0].data_ptr(), wf[1].data_ptr(),
+                                   _st()), "wd_gemm_pack_w")
+        return wf
+
+    w1f, w2f = pack(geglu_interleave(w1, 16)), pack(w2)
+    b1d, b2d, resd = geglu_interleave(b1, 16).to(DEV), b2.to(DEV), res.to(DEV)
+    xp = planes_of(x.to(DEV))
+    a = N.WdFfArgs()
+    a.x_hi, a.x_lo, a.x_ld = xp[0].data_ptr(), xp[1].data_ptr(), c
+    a.m, a.c, a.inner = m, c, inner
+    a.w1_hi, a.w1_lo, a.b1 = w1f[0].data_ptr(), w1f[1].data_ptr(), b1d.data_ptr()
+    a.w2_hi, a.w2_lo, a.b2 = w2f[0].data_ptr(), w2f[1].data_ptr(), b2d.data_ptr()
+    a.resid, a.resid_ld = resd.data_ptr(), c
+    out = torch.full((m, c), float("nan"), device=DEV)
+    opl = torch.zeros(2, m, c, dtype=torch.bfloat16, device=DEV)
+    a.out_f32, a.out_ld = out.data_ptr(), c
+    if planes:
+        a.out_hi, a.out_lo, a.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), c
+    a.hw_out, a.npass = 1, npass
+    N.check(lib.wd_ff_fused(C.byref(a), _st()), "wd_ff_fused")
+    torch.cuda.synchronize()
+    tol = 3e-5 if npass == 3 else 3e-2
+    assert rel_err(out.cpu(), ref) < tol
+    if planes:
+        assert rel_err(unplanes(opl).cpu(), ref) < tol
+    first = out.clone()
+    N.check(lib.wd_ff_fused(C.byref(a), _st()), "wd_ff_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    a.inner = 100
+    assert lib.wd_ff_fused(C.byref(a), _st()) == N.WD_EINVAL
+
+
 @pytest.mark.parametrize("B,hh,ww,cin,n,tile,ksplit", [(3, 8, 32, 64, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 0),
                                                         (3, 8, 32, 64, 320, 128160, 1), (5, 8, 8, 64, 640, 64320, 1)])
 def test_gemm_weights_to_registers_kernel_statistics(B, hh, ww, cin, n, tile, ksplit):

@@ -42,10 +42,21 @@ class WdGemmArgs(C.Structure):
                 ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32)]
 
 
+class WdFfArgs(C.Structure):
+    _fields_ = [("x_hi", _vp), ("x_lo", _vp), ("x_ld", C.c_int32), ("m", C.c_int32), ("c", C.c_int32), ("inner", C.c_int32),
+                ("w1_hi", _vp), ("w1_lo", _vp), ("b1", _vp), ("w2_hi", _vp), ("w2_lo", _vp), ("b2", _vp), ("resid", _vp),
+                ("resid_ld", C.c_int32), ("out_f32", _vp), ("out_ld", C.c_int32), ("out_hi", _vp), ("out_lo", _vp),
+                ("out_pl_ld", C.c_int32), ("w3_hi", _vp), ("w3_lo", _vp), ("b3", _vp), ("resid3", _vp), ("resid3_ld", C.c_int32),
+                ("stat_part", _vp), ("stat_cpg", C.c_int32), ("hw_out", C.c_int32), ("npass", C.c_int32)]
+
+
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
     "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
     "wd_gemm_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "wd_ff_fused": (_i, [C.POINTER(WdFfArgs), _vp]),
+    "wd_ff_supported": (_i, [_i, _i]),
+    "wd_ff_args_bytes": (_i, []),
     "wd_gemm_args_bytes": (_i, []),
     "wd_gn_nchunk": (_i, [_i]),
     "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -152,6 +163,9 @@ def lib() -> C.CDLL:
         fn.argtypes = args
     if l.wd_gemm_args_bytes() != C.sizeof(WdGemmArgs):  # a stale library beside newer Python (or the reverse)
         raise NativeError(f"{LIB_PATH}: wd_gemm_args is {l.wd_gemm_args_bytes()} bytes in the library, {C.sizeof(WdGemmArgs)} in "
+                          "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
+    if l.wd_ff_args_bytes() != C.sizeof(WdFfArgs):
+        raise NativeError(f"{LIB_PATH}: wd_ff_args is {l.wd_ff_args_bytes()} bytes in the library, {C.sizeof(WdFfArgs)} in "
                           "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     _lib = l
     return l

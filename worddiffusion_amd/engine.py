@@ -288,6 +288,8 @@ class UNetEngine:
         # 64 x 320 tiles with the weights loaded straight into the MFMA operand registers (csrc/wd_gemmw.hip): the 320-column
         # layers whose grid fills the chip without a K cut
         self.use_wdirect = os.environ.get("WDIFF_GEMM_WDIRECT", "1") != "0"
+        # GEGLU feed-forward + residual in one launch per 64-token panel, hidden activations on chip (csrc/wd_ff.hip)
+        self.fuse_ff = os.environ.get("WDIFF_FUSE_FF", "1") != "0"
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
@@ -399,6 +401,10 @@ class UNetEngine:
                     R.matrix(p + ".ff1.w", 2 * ffi, inner).fwd(tb.ff.net[0].proj.weight, g=g)
                     R.vector(p + ".ff1.b", tb.ff.net[0].proj.bias, g=g)
                     R.linear(p + ".ff2", tb.ff.net[2])
+                    if self.lib.wd_ff_supported(inner, ffi):
+                        # the fused feed-forward (csrc/wd_ff.hip): x | gate rows in blocks of 16, one MFMA tile each
+                        R.matrix(p + ".ff1f.w", 2 * ffi, inner).fwd(tb.ff.net[0].proj.weight, g=16)
+                        R.vector(p + ".ff1f.b", tb.ff.net[0].proj.bias, g=16)
         self.film_total = off
         self.kv_total = kvo
         ted = m.time_embed[2].out_features
@@ -553,10 +559,7 @@ class UNetEngine:
                    (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather)) and
                    ((m + 63) // 64) * (nrows // 320) >= 256)
         if wdirect:
-            if wname not in self._wf:
-                self._wf[wname] = torch.empty_like(wp)
-                self._pack_wf(wname, self._wf[wname], torch.cuda.current_stream(self.device).cuda_stream)
-            wf = self._wf[wname]
+            wf = self._wfrag(wname)
             a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
             a.w_layout, a.slab_rows = 3, getattr(srcs[0], "_same_w", 0) if srcs[0].ntaps == 9 else 0
             tile = 64320
@@ -892,20 +895,50 @@ class UNetEngine:
             # ---- GEGLU feed-forward
             if n3 is None:
                 n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
-            ffh = self._planes(P, M, 4 * inner)
-            self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1.w", M, hw, bias=self._w[p + ".ff1.b"],
-                       act=N.ACT_GEGLU, out_pl=ffh, tile=geglu_tile(4 * inner))
             last = di == len(mod.transformer_blocks) - 1
             tok = self._f32(P, M, inner)
             xpl = self._planes(P, M, inner) if last else None
-            self._gemm(ops, p + ".ff2", [self._src(ffh, 4 * inner)], p + ".ff2.w", M, hw, bias=self._w[p + ".ff2.b"],
-                       resid=tok2.data_ptr(), resid_ld=inner, out_f32=None if last else tok, out_ld=inner,
-                       out_pl=xpl)
+            ffi = tb.ff.net[2].in_features
+            if self.fuse_ff and (p + ".ff1f.w") in self._w and (M + 63) // 64 >= 192:
+                # one workgroup per 64 tokens: worth it once they fill the chip (the 8 x 32 level at batch >= 48)
+                self._ff_fused(ops, p, n3, tok2, M, inner, ffi, None if last else tok, xpl)
+            else:
+                ffh = self._planes(P, M, ffi)
+                self._gemm(ops, p + ".ff1", [self._src(n3, inner)], p + ".ff1.w", M, hw, bias=self._w[p + ".ff1.b"],
+                           act=N.ACT_GEGLU, out_pl=ffh, tile=geglu_tile(ffi))
+                self._gemm(ops, p + ".ff2", [self._src(ffh, ffi)], p + ".ff2.w", M, hw, bias=self._w[p + ".ff2.b"],
+                           resid=tok2.data_ptr(), resid_ld=inner, out_f32=None if last else tok, out_ld=inner,
+                           out_pl=xpl)
         out = self._f32(P, M, c)
         gg = self._gemm(ops, name + ".proj_out", [self._src(xpl, inner)], name + ".po.w", M, hw,
                         bias=self._w[name + ".po.b"], resid=x.t.data_ptr(), resid_ld=c, out_f32=out, out_ld=c,
                         want_stats=True)
         return Act(out, c, h, w, gg._stats, prod=gg)
+
+    def _wfrag(self, wname):
+        """The fragment-major image (wd_gemm_pack_w) of a packed matrix, kept up to date by refresh_weights."""
+        if wname not in self._wf:
+            self._wf[wname] = torch.empty_like(self._w[wname])
+            self._pack_wf(wname, self._wf[wname], torch.cuda.current_stream(self.device).cuda_stream)
+        return self._wf[wname]
+
+    def _ff_fused(self, ops, p, n3, resid, M, inner, ffi, out_f32, out_pl):
+        """x + FeedForward(LN3(x)) (unet.py:343-344, :122-149) as one wd_ff_fused launch."""
+        a = N.WdFfArgs()
+        lo_ok = self.npass == 3
+        a.x_hi, a.x_lo, a.x_ld = n3[0].data_ptr(), (n3[1].data_ptr() if lo_ok else None), n3.shape[2]
+        a.m, a.c, a.inner = M, inner, ffi
+        w1, w2 = self._wfrag(p + ".ff1f.w"), self._wfrag(p + ".ff2.w")
+        a.w1_hi, a.w1_lo, a.b1 = w1[0].data_ptr(), w1[1].data_ptr(), self._w[p + ".ff1f.b"].data_ptr()
+        a.w2_hi, a.w2_lo, a.b2 = w2[0].data_ptr(), w2[1].data_ptr(), self._w[p + ".ff2.b"].data_ptr()
+        a.resid, a.resid_ld = resid.data_ptr(), inner
+        if out_f32 is not None:
+            a.out_f32, a.out_ld = out_f32.data_ptr(), inner
+        if out_pl is not None:
+            a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), (out_pl[1].data_ptr() if lo_ok else None), out_pl.shape[2]
+        a.hw_out, a.npass = 1, self.npass
+        self._cur_plan.keep.append(a)
+        ops.append((self.lib.wd_ff_fused, (C.byref(a),), p + ".ff (fused)"))
 
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int, film_steps: int = 0) -> Plan:
