@@ -81,8 +81,9 @@ typedef struct wd_gemm_args {
     int32_t w_layout;     /* 0: w = [n][ktot].  1: "slab order" [stage][n][32], stage = (32-channel chunk, tap) of src0
                            * (chunk-major, tap-minor) followed by the 32-channel chunks of src1: selects the kernel that
                            * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2)
-                           * 3: fragment-major weights (wd_gemm_pack_w), 64 x 320 tiles, weights loaded straight into registers;
-                           *    statistics (stat_part) are then kept per 64-row chunk: nchunk = max(1, hw_out / 64) */
+                           * 3: fragment-major weights (wd_gemm_pack_w), loaded straight into registers; tile 64320 or 128160.
+                           *    Statistics (stat_part) are kept per row panel of the tile: nchunk = max(1, hw_out / 64) for the
+                           *    64-row tile */
     int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192
                            * w_layout 2 or 3: w as for 0 (2) / fragment-major (3), src[0] is a 3x3 / pad 1 / stride 1 convolution (9 taps, its usual
                            * gather table) over images of width slab_rows, src[1] (optional) an identity source: selects the

@@ -1299,140 +1299,6 @@ int launch(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
-// Combine + the consumer's GroupNorm for one 64-row x 40-column tile whose rows are ONE sample (hw_out == 64, wd_gemm_args::gn_*):
-// the slabs summed in ascending order, bias / FiLM row / residual, the fp32 result, the (sample, group) statistics - written to
-// stat_part exactly as the ordinary combine writes them (same summation order) - and SiLU?(GroupNorm(result)) as operand planes.
-// A thread's (at most three) rows stay in its registers between the statistics and the normalisation, so the wd_gn_apply
-// launch and its pass over the tensor disappear (ten of them on the 4x16 level of the base UNet).
-__device__ __forceinline__ void wd_reduce_gn_tile(const wd_gemm_args& a, float* ep, const int m0, const int n0, const int tid) {
-    constexpr int BM = 64, BN = 40, Q = BN / 4, NRL = 256 / Q, KEEP = (BM + NRL - 1) / NRL;
-    const int rl = tid / Q, c = (tid - rl * Q) * 4;
-    const bool live = rl < NRL;
-    const int no = n0 + c;
-    const long total = (long)a.m * a.n;
-    float4 v[KEEP];
-    bool ok[KEEP];
-#pragma unroll
-    for (int k = 0; k < KEEP; ++k) {
-        const int row = rl + k * NRL;
-        ok[k] = live && row < BM && m0 + row < a.m;
-        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok[k]) v[k] = *reinterpret_cast<const float4*>(a.ws + (long)(m0 + row) * a.n + no);
-    }
-    for (int sp = 1; sp < a.ksplit; ++sp) {
-        float4 q[KEEP];
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[k]) q[k] = *reinterpret_cast<const float4*>(a.ws + (long)sp * total + (long)(m0 + rl + k * NRL) * a.n + no);
-        }
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            v[k].x += q[k].x; v[k].y += q[k].y; v[k].z += q[k].z; v[k].w += q[k].w;
-        }
-    }
-    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f), rv = bx;
-    if (live && a.bias) bx = *reinterpret_cast<const float4*>(a.bias + no);
-    if (live && a.rowvec) rv = *reinterpret_cast<const float4*>(a.rowvec + (long)(m0 / a.hw_out) * a.rowvec_ld + no);
-    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
-#pragma unroll
-    for (int k = 0; k < KEEP; ++k) {
-        if (!ok[k]) continue;
-        const long m = m0 + rl + k * NRL;
-        v[k].x += bx.x; v[k].y += bx.y; v[k].z += bx.z; v[k].w += bx.w;
-        if (a.rowvec) {
-            v[k].x += rv.x; v[k].y += rv.y; v[k].z += rv.z; v[k].w += rv.w;
-        }
-        if (a.resid) {
-            const float4 q = *reinterpret_cast<const float4*>(a.resid + m * a.resid_ld + no);
-            v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w;
-        }
-        ssum.x += v[k].x; ssum.y += v[k].y; ssum.z += v[k].z; ssum.w += v[k].w;
-        ssq.x += v[k].x * v[k].x; ssq.y += v[k].y * v[k].y; ssq.z += v[k].z * v[k].z; ssq.w += v[k].w * v[k].w;
-        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + m * a.out_ld + no) = v[k];
-    }
-    // per-thread column sums -> (group, row lane) -> (group): the order of the ordinary combine
-    float* scr = ep;                                                  // [NRL][BN][2]
-    double* gs = reinterpret_cast<double*>(ep + NRL * BN * 2);        // [BN / stat_cpg][2]
-    if (live) {
-        float* o = scr + (rl * BN + c) * 2;
-        *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
-    }
-    __syncthreads();
-    const int cps = a.stat_cpg, ngt = BN / cps;
-    for (int it = tid; it < ngt * NRL; it += 256) {
-        const int l = it % NRL, g = it / NRL;
-        const float* p = scr + (l * BN + g * cps) * 2;
-        float su = 0.f, sq = 0.f;
-        for (int cc = 0; cc < cps; ++cc) {
-            su += p[2 * cc];
-            sq += p[2 * cc + 1];
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every read of this group's span precedes the write-back
-        scr[(l * BN + g * cps) * 2] = su;
-        scr[(l * BN + g * cps) * 2 + 1] = sq;
-    }
-    __syncthreads();
-    if (tid < ngt && n0 + tid * cps < a.n) {
-        double su = 0.0, sq = 0.0;
-        for (int l = 0; l < NRL; ++l) {
-            const float* p = scr + (l * BN + tid * cps) * 2;
-            su += (double)p[0];
-            sq += (double)p[1];
-        }
-        gs[2 * tid] = su;
-        gs[2 * tid + 1] = sq;
-        double* o = a.stat_part + ((long)(m0 / a.hw_out) * (a.n / cps) + n0 / cps + tid) * 2;  // (one chunk per sample: hw_out == BM)
-        o[0] = su;
-        o[1] = sq;
-    }
-    __syncthreads();
-    if (!live) return;
-    // the consumer's groups: gn_cpg channels = gn_cpg / stat_cpg statistics groups (wd_gn_apply's arithmetic)
-    const int gcp = a.gn_cpg, ratio = gcp / cps;
-    float sc[4], sh[4];
-    const float4 ga = *reinterpret_cast<const float4*>(a.gn_gamma + no);
-    const float4 be = *reinterpret_cast<const float4*>(a.gn_beta + no);
-    const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
-    int gprev = -1;
-    float mean = 0.f, rstd = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int g = (c + j) / gcp;
-        if (g != gprev) {
-            double ds = 0.0, dq = 0.0;
-            for (int k = 0; k < ratio; ++k) {
-                ds += gs[2 * (g * ratio + k)];
-                dq += gs[2 * (g * ratio + k) + 1];
-            }
-            const double n = (double)a.hw_out * gcp;
-            const double mu = ds / n;
-            double var = dq / n - mu * mu;
-            if (var < 0.0) var = 0.0;
-            mean = (float)mu;
-            rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
-            gprev = g;
-        }
-        sc[j] = rstd * gaa[j];
-        sh[j] = bea[j] - mean * sc[j];
-    }
-#pragma unroll
-    for (int k = 0; k < KEEP; ++k) {
-        if (!ok[k]) continue;
-        const long m = m0 + rl + k * NRL;
-        float4 y;
-        y.x = v[k].x * sc[0] + sh[0]; y.y = v[k].y * sc[1] + sh[1]; y.z = v[k].z * sc[2] + sh[2]; y.w = v[k].w * sc[3] + sh[3];
-        if (a.gn_silu) {
-            y.x = wd_silu(y.x); y.y = wd_silu(y.y); y.z = wd_silu(y.z); y.w = wd_silu(y.w);
-        }
-        uint2 hh, ll;
-        wd_split4(y, hh, ll);
-        *reinterpret_cast<uint2*>(a.out_hi + m * a.out_pl_ld + no) = hh;
-        if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + m * a.out_pl_ld + no) = ll;
-    }
-}
-
 // out = epilogue(sum of the ksplit partial slabs): one workgroup per BM x BN tile sums the slabs in a fixed order into
 // the same fp32 LDS image the in-kernel epilogue uses and then runs that epilogue (statistics included).
 template <int BM, int BN>
@@ -1447,7 +1313,7 @@ __global__ void __launch_bounds__(256) wd_gemm_reduce_kernel(const wd_gemm_args 
     const bool v4 = (a.n & 3) == 0;
     if constexpr (BM == 64 && BN == 40) {
         if (a.gn_gamma) {  // (the host has checked shapes and alignment: wd_gemm)
-            wd_reduce_gn_tile(a, ep, m0, n0, tid);
+            wd_gn_tile<40, 256, true>(a, nullptr, ep, m0, n0, tid);
             return;
         }
     }
@@ -2352,7 +2218,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         // fragment-major weights (wd_gemm_pack_w): the 64 x 320 weights-to-registers kernel only
         if (a.n % 160 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160) || a.ktot % 64) return WD_EINVAL;
         if (a.tile == 0) a.tile = 128160;
-        if (a.tile == 64320 && a.n % 320) return WD_EINVAL;
+        if (a.n % (a.tile % 1000)) return WD_EINVAL;
     }
     if (a.stat_part) {
         // fused GroupNorm statistics need row panels that tile the samples and whole groups inside a column tile

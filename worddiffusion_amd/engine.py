@@ -71,6 +71,11 @@ def geglu_interleave(w: torch.Tensor, g: int = 32) -> torch.Tensor:
     return torch.stack([x, gt], dim=1).reshape(w.shape)
 
 
+def ff_fused_supported(c: int, inner: int) -> bool:
+    """The shapes csrc/wd_ff.hip covers (== wd_ff_supported of the library, which wd_ff_fused itself enforces)."""
+    return c == 320 and inner > 0 and inner % 128 == 0
+
+
 def geglu_tile(inner: int) -> int:
     """GEMM tile for a GEGLU projection with ``inner`` output columns: 128x160 when 80 divides it."""
     return 128160 if inner % 80 == 0 else 128064
@@ -401,7 +406,7 @@ class UNetEngine:
                     R.matrix(p + ".ff1.w", 2 * ffi, inner).fwd(tb.ff.net[0].proj.weight, g=g)
                     R.vector(p + ".ff1.b", tb.ff.net[0].proj.bias, g=g)
                     R.linear(p + ".ff2", tb.ff.net[2])
-                    if self.lib.wd_ff_supported(inner, ffi):
+                    if ff_fused_supported(inner, ffi):
                         # the fused feed-forward (csrc/wd_ff.hip): x | gate rows in blocks of 16, one MFMA tile each
                         R.matrix(p + ".ff1f.w", 2 * ffi, inner).fwd(tb.ff.net[0].proj.weight, g=16)
                         R.vector(p + ".ff1f.b", tb.ff.net[0].proj.bias, g=16)
