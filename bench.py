@@ -428,6 +428,103 @@ def full_call_leg(model, args, dev, B, rank, world, barrier, wdist):
                 graph=diff.last_stats["graph"], output_finite=bool(torch.isfinite(lat).all().item()))
 
 
+CONTRACTION_CLASSES = {
+    0: "wd_gemm2_kernel<128,160,3,2,M16> (LDS-staged tap-gather split-bf16 MFMA GEMM: the 4x16-level convolutions, K cut over workgroups)",
+    6: "wd_gemm tiles other than 128x160",
+    8: "wd_gemm4_kernel (two workgroups per CU)",
+    9: "wd_gemmw_kernel<3,1> (64x320 tiles, A rows through LDS, fragment-major weights straight into the MFMA operand registers: "
+       "the 3x3 convolutions and 1x1 projections of the 8x32 level)",
+    10: "wd_ff_kernel<3> (GEGLU feed-forward + residual per 64-token panel, hidden activations on chip)",
+}
+PMC_KEYS = {0: "wd_gemm2_kernel<128, 160, 3, 2, false, true>", 9: "wd_gemmw_kernel<3, 1>", 10: "wd_ff_kernel<3, false>"}
+
+
+def streaming_bytes_per_step(P, lib, npl):
+    """Algorithmic HBM bytes per step of the streaming classes, from the launch plan's own arguments: GroupNorm apply (fp32 map in,
+    operand planes out), the folded cross-attention pair (tokens in, tokens + next-LayerNorm planes out) and the split-K combine
+    (slabs in, result + planes out)."""
+    by = {"gn_apply": 0.0, "attention": 0.0, "gemm_splitk_reduce": 0.0}
+    for fn, args, what in P.step:
+        name = getattr(fn, "__name__", "")
+        if name == "wd_gn_apply":
+            rows, c = args[2] * args[3], args[4]
+            by["gn_apply"] += rows * c * (4 + 2 * npl) + (rows * c * 2 * npl if args[17] else 0)
+        elif name == "wd_gn_apply2":
+            rows, c = args[14] * args[15], args[2] + args[9]
+            by["gn_apply"] += rows * c * (4 + 2 * npl) + (rows * c * 2 * npl if args[24] else 0)
+        elif name in ("wd_xattn_pair", "wd_xattn_fused"):
+            rows, c = args[2] * args[3], args[4]
+            by["attention"] += rows * c * (4 + 4 + 2 * npl)
+        elif name == "wd_gemm":
+            g = args[0]._obj
+            if g.w_layout != 3 and g.ws and g.ksplit == 0 and g.act == 0:
+                ks = lib.wd_gemm_auto_ksplit(g.m, g.n, g.ktot, g.ws_floats)
+                if ks > 1:
+                    by["gemm_splitk_reduce"] += g.m * g.n * (4 * ks + (4 if g.out_f32 else 0) + (2 * npl if g.out_hi else 0) +
+                                                               (4 if g.resid else 0))
+    return by
+
+
+def roofline_leg(runner, precision):
+    """Eager pass with a hipEvent pair around every launch on the launch stream (wd_prof_*): per-class time, algorithmic FLOP/s
+    against the dense bf16 MFMA peak for the contraction classes, algorithmic bytes/s against the HBM peak for the streaming ones.
+    The `roofline` object describes the class that takes the most time."""
+    from worddiffusion_amd import _native as N
+    lib = N.lib()
+    nprof = 3
+    with torch.cuda.stream(runner.stream):
+        st = runner.stream.cuda_stream
+        runner.reset_t()
+        runner.one_step(st)
+        torch.cuda.synchronize()
+        lib.wd_prof_enable(1)
+        for _ in range(nprof):
+            runner.one_step(st)
+        ms = (C.c_double * N.NCLASS)()
+        cnt = (C.c_int64 * N.NCLASS)()
+        fl = (C.c_double * N.NCLASS)()
+        lib.wd_prof_collect_flops(ms, cnt, fl)
+        lib.wd_prof_enable(0)
+    npl = 2 if precision == "bf16x3" else 1
+    sbytes = streaming_bytes_per_step(runner.P, lib, npl)
+    classes = {}
+    for i in range(N.NCLASS):
+        name = N.CLASS_NAMES[i]
+        d = dict(ms_per_step=ms[i] / nprof, launches_per_step=int(cnt[i]) // nprof)
+        if i in CONTRACTION_CLASSES and ms[i] > 0:
+            tf = fl[i] / (ms[i] * 1e-3) / 1e12
+            d.update(gflop_per_step=fl[i] / nprof / 1e9, tflops=tf, mfma_frac=tf / PEAK_BF16_TFLOPS)
+        if name in sbytes and ms[i] > 0:
+            gbs = sbytes[name] / (ms[i] / nprof * 1e-3) / 1e9
+            d.update(mb_per_step=sbytes[name] / 1e6, gb_per_s=gbs, hbm_frac=gbs / PEAK_HBM_GBS)
+        classes[name] = d
+    dom = max(CONTRACTION_CLASSES, key=lambda i: ms[i])
+    ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    traffic, traffic_note = None, "no PMC summary for this kernel under profiles/"
+    try:  # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/, per round)
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        name = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json"))[-1]  # the latest round's
+        k = json.load(open(os.path.join(pdir, name)))[PMC_KEYS[dom]]
+        traffic = (k["fetch_mb_corrected"] + k["write_mb"]) * 1e6
+        traffic_note = ("HBM bytes per launch of %s: %.1f MB fetched (FETCH_SIZE, gfx950 x2 correction) + %.1f MB written (WRITE_SIZE); "
+                        "separate rocprofv3 --pmc passes over this bench command, profiles/%s"
+                        % (PMC_KEYS[dom], k["fetch_mb_corrected"], k["write_mb"], name))
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
+    total_fl = sum(fl[i] for i in CONTRACTION_CLASSES)
+    total_ms = sum(ms[i] for i in range(N.NCLASS))
+    roof = dict(bound="mfma", kernel=CONTRACTION_CLASSES[dom] + "; hipEvent pair around every launch", achieved=ach,
+                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_note=traffic_note,
+                launches_per_step=int(cnt[dom]) // nprof, avg_launch_us=1e3 * ms[dom] / max(int(cnt[dom]), 1),
+                algorithmic_gflop_per_step=fl[dom] / nprof / 1e9, share_of_step_kernel_time=ms[dom] / total_ms if total_ms else None,
+                all_contractions=dict(gflop_per_step=total_fl / nprof / 1e9,
+                                      tflops=total_fl / (sum(ms[i] for i in CONTRACTION_CLASSES) * 1e-3) / 1e12),
+                mfma_issue_factor=3 if precision == "bf16x3" else 1,
+                note="achieved counts each multiply-add once; the split-bf16 path issues 3 MFMAs per product")
+    return roof, classes
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,46 +595,7 @@ def main():
     roof = None
     prof_extra = None
     if rank == 0 and not a.no_roofline:
-        # eager pass with a hipEvent pair around every launch on the launch stream (wd_prof_*): per-class time
-        from worddiffusion_amd import _native as N
-        lib = N.lib()
-        nprof = 3
-        with torch.cuda.stream(runner.stream):
-            st = runner.stream.cuda_stream
-            runner.reset_t()
-            runner.one_step(st)
-            torch.cuda.synchronize()
-            lib.wd_prof_enable(1)
-            for _ in range(nprof):
-                runner.one_step(st)
-            ms = (C.c_double * N.NCLASS)()
-            cnt = (C.c_int64 * N.NCLASS)()
-            fl = C.c_double()
-            lib.wd_prof_collect(ms, cnt, C.byref(fl))
-            lib.wd_prof_enable(0)
-        gemm_ms, gemm_n, gemm_flops = ms[0], cnt[0], fl.value
-        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/, per round)
-            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            name = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json"))[-1]  # the latest round's
-            pmc = json.load(open(os.path.join(pdir, name)))
-            k = pmc["wd_gemm2_kernel<128, 160, 3, 2, false, true>"]
-            traffic = (k["fetch_mb_corrected"] + k["write_mb"]) * 1e6
-            traffic_note = ("HBM bytes per launch of wd_gemm2_kernel<128,160,3,2,M16> (its 256-workgroup launches): %.1f MB fetched (FETCH_SIZE, gfx950 x2 "
-                            "correction) + %.1f MB written (WRITE_SIZE); separate rocprofv3 --pmc passes over this bench "
-                            "command, profiles/%s" % (k["fetch_mb_corrected"], k["write_mb"], name))
-        except (OSError, KeyError, ValueError, IndexError):
-            traffic, traffic_note = None, "no PMC summary under profiles/"
-        roof = dict(bound="mfma", kernel="wd_gemm2_kernel<128,160,3,2> (tap-gather split-bf16 MFMA GEMM: the 3x3 convolutions, "
-                                         "1x1 / linear projections and GEGLU of the step; hipEvent pair around every launch)",
-                    achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_note=traffic_note,
-                    launches_per_step=gemm_n // nprof, avg_launch_us=1e3 * gemm_ms / max(gemm_n, 1),
-                    algorithmic_gflop_per_step=gemm_flops / nprof / 1e9,
-                    mfma_issue_factor=3 if a.precision == "bf16x3" else 1,
-                    note="achieved counts each multiply-add once; the split-bf16 path issues 3 MFMAs per product")
-        prof_extra = {N.CLASS_NAMES[i]: dict(ms_per_step=ms[i] / nprof, launches_per_step=int(cnt[i]) // nprof)
-                      for i in range(N.NCLASS)}
+        roof, prof_extra = roofline_leg(runner, a.precision)
 
     phosc_extra = None
     if rank == 0 and world == 1 and a.variant == "base" and not a.no_phosc:
@@ -572,7 +630,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.variant == "base":
         usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cpu = cpu_baseline(min(usable, 64))
+        phys = cpu_info().get("physical_cores") or usable
+        cpu = cpu_baseline(max(1, min(usable, phys)))  # N = physical cores (as far as the affinity mask allows)
 
     train = None
     if a.train_steps < 0:
@@ -602,9 +661,12 @@ def main():
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                     scaling="weak", vs_baseline=None,
                     dtype="bf16x3" if a.precision == "bf16x3" else "bf16", data="synthetic",
-                    config=dict(workload="BASELINE configs[1]: batch 64 per GPU of 64x256 crops = [64,4,8,32] latents, "
-                                         "1000-step DDPM (999 executed steps), base unet.py UNetModel (320 ch, mult (1,1), "
-                                         "4 heads, 339 writers), random-init synthetic weights",
+                    config=dict(workload=("%s: batch %d per GPU of 64x256 crops = [%d,4,8,32] latents, 1000-step DDPM (999 executed "
+                                          "steps), %s (320 ch, mult (1,1), 4 heads, 339 writers), random-init synthetic weights"
+                                          % ("BASELINE configs[1]" if (a.variant == "base" and B == BATCH) else
+                                             ("BASELINE configs[4], one GPU's share" if a.variant == "phosc" else "configs[1] model at another batch"),
+                                             B, B, "base unet.py UNetModel" if a.variant == "base" else
+                                             "unetPhosc.py UNetModelPhosc (args.phosc = 1, 10 word ids + 769-int PHOSC vector)")),
                                 variant=a.variant, batch_per_gpu=B, noise_steps=T, executed_steps_per_image=T - 1, forwards_per_step=1,
                                 precision=("split-bf16 MFMA x3, fp32 accumulate (<=1e-4 of the fp32 reference)"
                                            if a.precision == "bf16x3" else "bf16 MFMA single pass (outside 1e-3 parity)"),

@@ -450,12 +450,15 @@ int wd_graph_launch(void* graph_exec, void* stream);
 int wd_graph_destroy(void* graph_exec);
 
 /* per-kernel-class timing with hipEvents recorded on the launch stream (bench.py roofline leg).
- * classes: 0 gemm (the dominant wd_gemm2_kernel<128,160,...>; gemm_flops counts its 2*M*N*K), 1 gn_stats, 2 gn_apply,
- * 3 layernorm, 4 attention, 5 other, 6 gemm with other tile shapes, 7 split-K combine pass, 8 the two-workgroups-per-CU
- * gemm kernel (wd_gemm4_kernel). */
-#define WD_NCLASS 9
+ * classes: 0 gemm (the LDS-staged wd_gemm2_kernel<128,160,...>), 1 gn_stats, 2 gn_apply, 3 layernorm, 4 attention, 5 other,
+ * 6 gemm with other tile shapes, 7 split-K combine pass, 8 the two-workgroups-per-CU gemm kernel (wd_gemm4_kernel),
+ * 9 the weights-to-registers gemm (wd_gemmw_kernel, 64 x 320 / 128 x 160 tiles), 10 the fused feed-forward (wd_ff_kernel).
+ * wd_prof_collect: gemm_flops = the 2*M*N*K of class 0; wd_prof_collect_flops additionally returns the algorithmic FLOPs
+ * (each multiply-add counted once) of every class that declares them (the contraction classes 0, 6, 8, 9, 10). */
+#define WD_NCLASS 11
 int wd_prof_enable(int on);
 int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
+int wd_prof_collect_flops(double* ms_per_class, int64_t* launches_per_class, double* flops_per_class); /* syncs */
 
 const char* wd_version(void);
 int wd_device_info(int* cu_count, int* lds_per_block, char* name, int name_len);

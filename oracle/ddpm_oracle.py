@@ -96,12 +96,13 @@ def sampling3_calls_model(i: int, noise_steps: int, epoch: int = 0) -> bool:
 
 
 def sampling3(model: Callable, x_T: torch.Tensor, noise_steps: int, epoch: int = 0, full_sampling: bool = False,
-              noises: Optional[Sequence[torch.Tensor]] = None):
+              noises: Optional[Sequence[torch.Tensor]] = None, record: Optional[list] = None):
     """regenerateFromtrain2.py:521-618 (``sampling3``): the predicted noise is refreshed only on the steps of
     ``sampling3_calls_model`` and reused in between; without ``fullSampling`` the update drops the noise term
-    (``x = 1/sqrt(alpha) * (x - (1-alpha)/sqrt(1-alpha_hat) * eps)``, :618).  PARITY UNPINNED: the script cannot be imported
-    (its ``unetOriginal`` / ``utils.*`` / ``htr.*`` dependencies are not in the reference), so this restates the published
-    loop and no golden vector exists for it."""
+    (``x = 1/sqrt(alpha) * (x - (1-alpha)/sqrt(1-alpha_hat) * eps)``, :618).  PINNED by ``tests/golden/ddpm_traj_sampling3.npz``:
+    trajectories recorded from that script's own ``Diffusion.sampling3`` (``oracle/make_golden_sampling3.py`` imports it with
+    empty stand-ins for the modules its import lines name and the sampler never touches).  ``record`` receives the x handed
+    to the model on every model call."""
     beta, alpha, alpha_hat = schedule(noise_steps)
     x = x_T
     eps_hat = None
@@ -110,6 +111,8 @@ def sampling3(model: Callable, x_T: torch.Tensor, noise_steps: int, epoch: int =
     for i in reversed(range(1, noise_steps)):
         t = (torch.ones(x.shape[0]) * i).long()
         if full_sampling or sampling3_calls_model(i, noise_steps, epoch):
+            if record is not None:
+                record.append(x.clone())
             eps_hat = model(x, t)
             calls += 1
         z = None

@@ -251,6 +251,27 @@ def test_full_size_properties_b64():
     assert max_rel(o1[:2].cpu(), ref) < 1e-4
 
 
+def test_full_size_properties_b64_phosc():
+    """BASELINE configs[4]'s one-GPU share at the benchmark batch: UNetModelPhosc (args.phosc = 1), 320 channels, 10 word ids +
+    the 769-int PHOSC vector (779-key cross-attention, 256-key self-attention), B = 64 - determinism, per-sample independence
+    (sample b of the batch == the same sample run alone) and two samples against the oracle."""
+    m = build(FULL, "phosc", True, seed=0)
+    inp = synthetic_inputs(64, seed=4, phosc_len=769)
+    o1 = call(m, "phosc", inp["x"], inp["t"], inp["context"], inp["y"], inp["phosc"])
+    o2 = call(m, "phosc", inp["x"], inp["t"], inp["context"], inp["y"], inp["phosc"])
+    assert o1.shape == (64, 4, 8, 32) and torch.equal(o1, o2) and torch.isfinite(o1).all()
+    for b in (0, 33, 63):
+        ob = call(m, "phosc", inp["x"][b:b + 1], inp["t"][b:b + 1], inp["context"][b:b + 1], inp["y"][b:b + 1], inp["phosc"][b:b + 1])
+        assert max_rel(ob.cpu(), o1[b:b + 1].cpu()) < 5e-5, b
+    shapes = U.state_dict_shapes(FULL, "phosc")
+    from worddiffusion_amd.synthetic import synthetic_tensor
+    sd = {k: torch.from_numpy(synthetic_tensor(k, s, 0)) for k, s in shapes}
+    orc = U.UNetOracle(FULL, sd, "phosc", True)
+    with torch.no_grad():
+        ref = orc(inp["x"][:2], inp["t"][:2], inp["context"][:2], inp["y"][:2], inp["phosc"][:2])
+    assert max_rel(o1[:2].cpu(), ref) < 1e-4
+
+
 def test_optimizer_side_of_train_step(golden_dir):
     """MSE loss / gradient and the fused AdamW(+EMA) launch against the reference's own train step
     (tests/golden/train_step.npz: loss, AdamW-updated tensors) and torch.optim.AdamW semantics."""

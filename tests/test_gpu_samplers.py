@@ -31,8 +31,8 @@ class IdentityVAE:
         return types.SimpleNamespace(sample=z)
 
 
-def _phosc_model(cfg, seed):
-    m = UNetModelPhosc(args=make_args(device=DEV, phosc=1), **cfg)
+def _phosc_model(cfg, seed, phosc=1):
+    m = UNetModelPhosc(args=make_args(device=DEV, phosc=phosc), **cfg)
     return fill_module_(m, seed).to(DEV).eval()
 
 
@@ -62,6 +62,45 @@ def test_phosc_sampling_loop_matches_reference(golden_dir, tag, cfg, hw, use_gra
     assert float((a - torch.from_numpy(g["image"])).abs().max()) < 1e-3
     with pytest.raises(ValueError):
         diff.sampling(m, None, n, str(g["word"]), labels, args)  # args.phosc = 1 without a PHOSC vector
+
+
+@pytest.mark.parametrize("tag", ["skip", "full", "phosc"])
+def test_step_skipping_sampler_matches_reference(golden_dir, tag):
+    """Diffusion.sampling3 (same argument order as regenerateFromtrain2.py:465) against the trajectories recorded from the
+    reference's own class on its hard-coded 600-step schedule: the UNet on 120 of 599 iterations + deterministic update,
+    fullSampling (every step, recorded draws), the PHOSC call form from a given x_t at epoch 12.  Graph replay == eager."""
+    g = load_golden(golden_dir, "ddpm_traj_sampling3")
+    full, epoch = bool(g[tag + "_full"]), int(g[tag + "_epoch"])
+    words = [str(w) for w in g[tag + "_words"]]
+    n = len(words)
+    phosc_on = (tag + "_phosc") in g.files
+    m = _phosc_model(SMALL, int(g[tag + "_seed"]), phosc=1 if phosc_on else 0)
+    args = make_args(device=DEV, phosc=1 if phosc_on else 0)
+    args.fullSampling = full
+    diff = Diffusion(noise_steps=600, img_size=(32, 64), args=args)
+    labels = torch.from_numpy(g[tag + "_labels"])
+    phosc = torch.from_numpy(g[tag + "_phosc"]) if phosc_on else None
+    noise = torch.from_numpy(g[tag + "_noise"])
+    ni = int(g[tag + "_noise_input"])
+    x_t = torch.from_numpy(g[tag + "_x_t"])
+    kw = dict(x_T=noise[0], noise=list(noise[1:]) if full else None)
+    rec = []
+    x0 = diff.sampling3(epoch, x_t, words, phosc, m, m, None, 0, ni, n, words, labels, args, record=rec, **kw)
+    assert diff.last_stats["model_calls"] == int(g[tag + "_calls"])
+    # the reference records the x handed to the model on every 10th model call
+    called = [i for i in reversed(range(1, 600)) if full or Diffusion.sampling3_calls_model(i, 600, epoch)]
+    steps = list(reversed(range(1, 600)))
+    xs = torch.stack([rec[steps.index(i)].cpu() for i in called[::10]])
+    ref = g[tag + "_x_every10calls"]
+    assert xs.shape == tuple(ref.shape)
+    for i in range(xs.shape[0]):
+        assert max_rel(xs[i], ref[i]) < 1e-3, (tag, i)
+    assert max_rel(x0.cpu(), g[tag + "_x_final"]) < 1e-3
+    zero, imgs, img = diff.sampling3(epoch, x_t, words, phosc, m, m, IdentityVAE(), 0, ni, n, words, labels, args, **kw)
+    assert zero == 0 and float((img.cpu() - torch.from_numpy(g[tag + "_image"])).abs().max()) < 5e-3
+    x1 = diff.sampling3(epoch, x_t, words, phosc, m, m, None, 0, ni, n, words, labels, args, use_graph=False, **kw)
+    x2 = diff.sampling3(epoch, x_t, words, phosc, m, m, None, 0, ni, n, words, labels, args, use_graph=True, **kw)
+    assert torch.equal(x1, x2) and torch.equal(x1, x0)
 
 
 def test_modify_condition_sampling_loop_matches_reference(golden_dir):

@@ -135,6 +135,41 @@ def test_modify_condition_sampling_loop_and_alphabet(golden_dir):
         assert float((img - torch.from_numpy(g[tag + "_image"])).abs().max()) < 2e-4, tag
 
 
+@pytest.mark.parametrize("tag", ["skip", "full", "phosc"])
+def test_step_skipping_sampler_matches_reference(golden_dir, tag):
+    """regenerateFromtrain2.Diffusion.sampling3 (:465-648) as recorded from the reference's own class (600-step schedule; UNet on
+    120 of the 599 iterations without fullSampling, deterministic update; every iteration and the stochastic update with it;
+    PHOSC call form, start from a given x_t, epoch 12): oracle loop == recorded trajectory."""
+    g = load_golden(golden_dir, "ddpm_traj_sampling3")
+    assert str(g["lang"]) == "ENG" and int(g["max_chars"]) == D.MAX_CHARS and int(g["noise_steps"]) == 600
+    for w, ref in zip(("MOVE", "a", "getting"), g["label_padding"]):
+        assert D.label_padding(w) == [int(v) for v in ref]
+    full, epoch = bool(g[tag + "_full"]), int(g[tag + "_epoch"])
+    words = [str(w) for w in g[tag + "_words"]]
+    phosc_on = (tag + "_phosc") in g.files
+    orc = _oracle(SMALL, "phosc", int(g[tag + "_seed"]), phosc_on)
+    ctx = torch.tensor([D.label_padding(w) for w in words], dtype=torch.int64)
+    y = torch.from_numpy(g[tag + "_labels"])
+    phosc = torch.from_numpy(g[tag + "_phosc"]) if phosc_on else None
+    noise = torch.from_numpy(g[tag + "_noise"])
+    assert int(g[tag + "_ndraws"]) == 599  # the start x + one draw per step i > 1 (made even where the update ignores it)
+    x_start = torch.from_numpy(g[tag + "_x_t"]) if int(g[tag + "_noise_input"]) == 0 else noise[0]
+    rec = []
+    with torch.no_grad():
+        x0, calls = D.sampling3(lambda x, t: orc(x, t, ctx, y, phosc) if phosc_on else orc(x, t, ctx, y), x_start, 600, epoch, full,
+                                list(noise[1:]) if full else None, rec)
+    assert calls == int(g[tag + "_calls"]) == (599 if full else 120)
+    xs = torch.stack(rec[::10])
+    ref = g[tag + "_x_every10calls"]
+    assert xs.shape == tuple(ref.shape)
+    # (|x| grows over the trajectory with random weights: compare each recorded state at its own scale)
+    for i in range(xs.shape[0]):
+        assert max_rel(xs[i], ref[i]) < 2e-4, (tag, i)
+    assert max_rel(x0, g[tag + "_x_final"]) < 2e-4
+    img = ((x0 / 0.18215) / 2 + 0.5).clamp(0, 1)
+    assert float((img - torch.from_numpy(g[tag + "_image"])).abs().max()) < 2e-3
+
+
 def test_train_step(golden_dir):
     from worddiffusion_amd.synthetic import synthetic_tensor
     g = load_golden(golden_dir, "train_step")

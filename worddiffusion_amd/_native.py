@@ -15,9 +15,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wdiff_hip.h")
 
 WD_OK, WD_EINVAL, WD_ELAUNCH, WD_ESTATE = 0, -1, -2, -3
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
-NCLASS = 9
+NCLASS = 11
 CLASS_NAMES = ("gemm", "gn_stats", "gn_apply", "layernorm", "attention", "other", "gemm_other_tiles", "gemm_splitk_reduce",
-               "gemm_two_per_cu")
+               "gemm_two_per_cu", "gemm_weights_to_registers", "feed_forward_fused")
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -129,6 +129,7 @@ _SIGS = {
     "wd_graph_destroy": (_i, [_vp]),
     "wd_prof_enable": (_i, [_i]),
     "wd_prof_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "wd_prof_collect_flops": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "wd_version": (C.c_char_p, []),
     "wd_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
 }

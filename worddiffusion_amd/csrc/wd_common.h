@@ -14,6 +14,8 @@
 #define WD_CLS_GEMM_OTHER 6   // wd_gemm tile shapes other than the dominant 128x160 kernel
 #define WD_CLS_GEMM_REDUCE 7  // split-K combine pass
 #define WD_CLS_GEMM_2CU 8     // wd_gemm4_kernel (two workgroups per CU)
+#define WD_CLS_GEMM_WDIRECT 9 // wd_gemmw_kernel (weights straight to registers)
+#define WD_CLS_FF 10          // wd_ff_kernel (fused GEGLU feed-forward)
 
 // ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
 extern "C" int wd_prof_is_on();

@@ -241,7 +241,7 @@ int launch_ff(const wd_ff_args& a, hipStream_t st) {
     }
     const int nb = (a.m + FBM - 1) / FBM;
     const double fl = 2.0 * (double)a.m * (3.0 * (double)a.inner * FC);
-    WdLaunchScope scope(WD_CLS_GEMM, st, fl);
+    WdLaunchScope scope(WD_CLS_FF, st, fl);
     hipLaunchKernelGGL((wd_ff_kernel<NPASS, PROJ>), dim3(nb), dim3(FNT), smem, st, a);
     return wd_check_launch();
 }

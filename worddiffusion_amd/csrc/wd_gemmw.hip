@@ -375,7 +375,7 @@ int launchw(const wd_gemm_args& a, hipStream_t st) {
     }
     const int nbn = a.n / BN, nbm = (a.m + BM - 1) / BM;
     {
-        WdLaunchScope scope(WD_CLS_GEMM, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        WdLaunchScope scope(WD_CLS_GEMM_WDIRECT, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
         hipLaunchKernelGGL((wd_gemmw_kernel<NPASS, RH>), dim3(nbn * nbm * a.ksplit), dim3(WNT), smem, st, a, nbn, nbm);
     }
     if (a.ksplit > 1) return wd_gemm_launch_reduce(a, st, BM);

@@ -35,27 +35,33 @@ extern "C" int wd_prof_enable(int on) {
     return WD_OK;
 }
 
-extern "C" int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops) {
+extern "C" int wd_prof_collect_flops(double* ms_per_class, int64_t* launches_per_class, double* flops_per_class) {
     if (!ms_per_class || !launches_per_class) return WD_EINVAL;
     if (hipDeviceSynchronize() != hipSuccess) return WD_ELAUNCH;
     for (int i = 0; i < WD_NCLASS; ++i) {
         ms_per_class[i] = 0.0;
         launches_per_class[i] = 0;
+        if (flops_per_class) flops_per_class[i] = 0.0;
     }
-    double fl = 0.0;
     for (auto& r : g_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.cls >= 0 && r.cls < WD_NCLASS) {
             ms_per_class[r.cls] += ms;
             launches_per_class[r.cls] += 1;
-            if (r.cls == WD_CLS_GEMM) fl += r.flops;
+            if (flops_per_class) flops_per_class[r.cls] += r.flops;
         }
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
     }
     g_recs.clear();
-    if (gemm_flops) *gemm_flops = fl;
     return WD_OK;
+}
+
+extern "C" int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops) {
+    double fl[WD_NCLASS];
+    const int rc = wd_prof_collect_flops(ms_per_class, launches_per_class, fl);
+    if (rc == WD_OK && gemm_flops) *gemm_flops = fl[WD_CLS_GEMM];
+    return rc;
 }
 
 extern "C" int wd_graph_begin(void* stream) {

@@ -75,10 +75,10 @@ class EMA:
             assert ma.is_contiguous() and cur.is_contiguous() and ma.dtype == torch.float32
             N.check(lib.wd_ema_update(ma.data_ptr(), cur.data_ptr(), ma.numel(), float(self.beta),
                                       _stream_ptr(ma.device)), "wd_ema_update")
-        # the kernel wrote the averaged parameters behind autograd's back: bump their version counters so that the engine of
-        # ``ma_model`` (which keys its packed operands on them, engine._signature) repacks before the next forward / sampling
-        touched = list(ma_model.parameters())
-        torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])
+        # the kernel wrote the averaged parameters behind autograd's back: the engine of ``ma_model`` (which keys its packed
+        # operands on the parameters' state, engine._signature) must repack before the next forward / sampling
+        from .engine import note_native_write
+        note_native_write()
 
     def step_ema(self, ema_model, model, step_start_ema=2000):
         if self.step < step_start_ema:
@@ -302,13 +302,15 @@ class Diffusion:
 
     @torch.no_grad()
     def sampling3(self, epoch, x_t, words, phoscLabels, model, model1, vae, emaOld, noiseInput, n, x_text, labels, args,
-                  mix_rate=None, cfg_scale=3, seed=None, sample_offset=0, use_graph=True):
+                  mix_rate=None, cfg_scale=3, seed=None, sample_offset=0, use_graph=True, x_T=None, noise=None, record=None):
         """Bulk-regeneration sampler of ``regenerateFromtrain2.py:465-648`` (same argument order): the predicted noise is
         refreshed only on the steps of ``sampling3_calls_model`` (1 in 5) and reused in between, and unless
         ``args.fullSampling`` the update is deterministic (no ``sqrt(beta) * noise`` term, ``:618``).  ``noiseInput == 0``
         starts from ``x_t`` instead of fresh noise (``:518-519``).  Returns ``(0, [images], images)`` like the reference when
         a ``vae`` is given, the denoised latents otherwise.  The per-step ``flagGen.txt`` poll (``:523-530``) is not
-        reproduced.  Parity: restated loop, no reference vector exists (the script is not importable) - see the oracle."""
+        reproduced.  ``x_T`` / ``noise`` / ``record`` (as in ``sampling``): the start latent, the per-step draws and a list that
+        receives every step's x - how the tests replay the trajectories recorded from the reference's own loop
+        (``tests/golden/ddpm_traj_sampling3.npz``, ``oracle/make_golden_sampling3.py``)."""
         if mix_rate is not None:
             raise NotImplementedError("mix_rate interpolation (unet.py:1558-1573)")
         if emaOld == 1:
@@ -329,8 +331,8 @@ class Diffusion:
             phosc = phoscLabels.int()
         full = bool(getattr(args, "fullSampling", False))
         T = self.noise_steps
-        x = self._denoise(model, n, tf, labels, phosc, device, x_T=x_t if noiseInput == 0 else None, seed=seed,
-                          sample_offset=sample_offset, use_graph=use_graph,
+        x = self._denoise(model, n, tf, labels, phosc, device, x_T=x_t if noiseInput == 0 else x_T, noise=noise, seed=seed,
+                          sample_offset=sample_offset, record=record, use_graph=use_graph,
                           calls_model=None if full else (lambda i: self.sampling3_calls_model(i, T, epoch)),
                           deterministic=not full)
         if vae is None:

@@ -115,6 +115,16 @@ def slab_span(tab: Optional[np.ndarray], hw_out: int, hw_src: int, m: int, bm: i
 
 
 _PARAM_GEN = [0]  # bumped whenever any nn.Module registers a Parameter (see UNetEngine._signature)
+_NATIVE_WRITES = [0]  # bumped whenever a kernel of this package rewrites parameters in place (optimiser step, EMA)
+
+
+def note_native_write():
+    """``wd_adamw_multi`` / ``wd_ema_update`` change parameter storage behind autograd's back (no ``Tensor._version`` bump): every
+    engine re-derives its packed operands before its next use.  (A public counter of our own instead of the private
+    ``torch._C._autograd._unsafe_set_version_counter``.)"""
+    _NATIVE_WRITES[0] += 1
+
+PLAN_CACHE_SIZE = int(os.environ.get("WDIFF_PLAN_CACHE", "4"))  # launch plans kept per engine (least recently used evicted)
 
 
 def _bump_param_gen(*_a):
@@ -452,7 +462,7 @@ class UNetEngine:
         if self._ps is None or self._ps_gen != _PARAM_GEN[0]:
             self._ps, self._ps_gen = list(self.model.parameters()), _PARAM_GEN[0]
         ps = self._ps
-        return (sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), str(ps[0].device))
+        return (sum(p._version for p in ps) + (_NATIVE_WRITES[0] << 32), hash(tuple(p.data_ptr() for p in ps)), str(ps[0].device))
 
     def refresh_weights(self, force: bool = False):
         """Re-derives the packed operands from the parameters when they changed (optimiser step, load_state_dict,
@@ -952,7 +962,10 @@ class UNetEngine:
         ``sampling()`` call instead of three 64-row GEMMs per step - and each step copies its rows (``wd_select_rows``)."""
         key = (B, H, W, ctx_len, phosc_len, self.npass, film_steps)
         if key in self._plans:
+            self._plans[key] = self._plans.pop(key)  # most recently used last
             return self._plans[key]
+        while len(self._plans) >= max(1, PLAN_CACHE_SIZE):  # a plan holds ~1 GB of buffers at B = 64: keep a few shapes only
+            self._plans.pop(next(iter(self._plans)))
         m = self.model
         lib = self.lib
         if ctx_len + phosc_len == 0:

@@ -144,7 +144,7 @@ class FusedAdamW:
         N.check(lib.wd_adamw_multi(self._table.data_ptr(), len(self.params), self._chunks, float(self.lr),
                                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                    self.step_count, mode, float(self.ema_beta), st), "wd_adamw_multi")
-        # the kernel changed the parameters behind autograd's back: bump the version counters so that every observer
-        # of Tensor._version (the engine's weight repack among them) sees the update
-        touched = self.params + (self.ema_params if (self.ema_params is not None and mode) else [])
-        torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])
+        # the kernel changed the parameters (and the EMA copy) behind autograd's back: the engines that packed operands from
+        # them must repack before their next use
+        from .engine import note_native_write
+        note_native_write()

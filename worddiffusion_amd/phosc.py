@@ -61,27 +61,23 @@ def phos_vector(word: str, index: Dict[str, int], table: np.ndarray) -> np.ndarr
     return np.concatenate([count(word)] + [count(s) for s in _segments(word)], axis=0)
 
 
+# PHOC character axis per version (phoc_generator.py:17-47): digits, then a-z, then the three Norwegian letters; version 'gw' has
+# no branch there, so nothing is ever set (36 zeros).
+_PHOC_AXIS = {"eng": "0123456789abcdefghijklmnopqrstuvwxyz", "nor": "0123456789abcdefghijklmnopqrstuvwxyzæøå", "gw": ""}
+_PHOC_SIZE = {"eng": 36, "nor": 39, "gw": 36}
+
+
 def _chars(seg: str, version: str) -> List[int]:
-    size = 39 if version == "nor" else 36
-    vector = [0] * size
+    """Character-presence vector of one segment: one table lookup per character.  A digit or letter outside the version's axis is an
+    index error, as in the reference (its ``ord`` offset lands past the vector); anything else is skipped."""
+    axis = _PHOC_AXIS[version]
+    vector = [0] * _PHOC_SIZE[version]
     for ch in seg:
-        if version == "eng":
-            if ch.isdigit():
-                vector[ord(ch) - ord('0')] = 1
-            elif ch.isalpha():
-                vector[10 + ord(ch) - ord('a')] = 1
-        elif version == "nor":
-            if ch.isdigit():
-                vector[ord(ch) - ord('0')] = 1
-            elif ch.isalpha():
-                if ch == 'æ':
-                    vector[36] = 1
-                elif ch == 'ø':
-                    vector[37] = 1
-                elif ch == 'å':
-                    vector[38] = 1
-                else:
-                    vector[10 + ord(ch) - ord('a')] = 1
+        pos = axis.find(ch)
+        if pos >= 0:
+            vector[pos] = 1
+        elif axis and (ch.isdigit() or ch.isalpha()):
+            raise IndexError(f"PHOC: {ch!r} is not on the {version!r} character axis")
     return vector
 
 
