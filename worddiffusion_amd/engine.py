@@ -572,6 +572,8 @@ class UNetEngine:
         wdirect = (self.use_wdirect and not span and not self.use_conv3 and w_row_off == 0 and n is None and act == N.ACT_NONE and
                    tile == 0 and nrows % 320 == 0 and ktot % 64 == 0 and all(s.c % 64 == 0 for s in srcs) and srcs[0].ntaps <= 9 and
                    (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather)) and
+                   # (the K-cut layers of the 4 x 16 level stay on the LDS-staged kernel: this one is 5 % faster on their long loops
+                   # in isolation and 2 % slower inside the step)
                    ((m + 63) // 64) * (nrows // 320) >= 256)
         if wdirect:
             wf = self._wfrag(wname)
@@ -718,7 +720,9 @@ class UNetEngine:
             return False
         if hw != 64 or pr.hw_out != 64 or pr.m % 64 or s.c % 160 or 40 % cpg or cpg % pc or nchunk != 1 or coff % 4:
             return False
-        if pr.act != N.ACT_NONE or pr.resid_rows or pr.ksplit != 0 or pr.tile != 0 or pr.w_layout == 1 or pr.dbg:
+        if pr.act != N.ACT_NONE or pr.resid_rows or pr.ksplit != 0 or pr.w_layout == 1 or pr.dbg:
+            return False
+        if pr.tile != (64320 if pr.w_layout == 3 else 0):
             return False
         return self.lib.wd_gemm_auto_ksplit(pr.m, pr.n, pr.ktot, pr.ws_floats) > 1
 
