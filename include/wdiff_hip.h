@@ -136,7 +136,10 @@ int wd_gemm_pack_w(const wd_bf16* hi, const wd_bf16* lo, int n, int ktot, wd_bf1
  * gate rows (unet.py:128 chunk(2): x = rows [0, inner), gate = rows [inner, 2 inner)); b1 in the same order.  w2: wd_gemm_pack_w
  * image of the [c][inner] output projection.  The hidden activations never leave the chip.  The result goes through the GEMM
  * epilogue: fp32 out_f32 and / or split-bf16 planes out_hi / out_lo, optional GroupNorm statistics (stat_part per 64-row panel:
- * nchunk = max(1, hw_out / 64), as wd_gemm with 64-row tiles).  w3 / b3 / resid3: reserved (must be NULL). */
+ * nchunk = max(1, hw_out / 64), as wd_gemm with 64-row tiles).
+ * w3 != NULL: the 1x1 proj_out of the SpatialTransformer and its residual ride in the same launch (unet.py:406-412),
+ *     out = resid3 + (resid + GEGLU(...) W2^T + b2) W3^T + b3
+ * with w3 the wd_gemm_pack_w image of the [c][c] projection; the feed-forward result itself is then not stored. */
 typedef struct wd_ff_args {
     const wd_bf16* x_hi;
     const wd_bf16* x_lo;

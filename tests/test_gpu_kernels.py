@@ -340,6 +340,28 @@ def test_fused_geglu_feed_forward(m, inner, npass, planes):
     assert torch.equal(first, out)
     a.inner = 100
     assert lib.wd_ff_fused(C.byref(a), _st()) == N.WD_EINVAL
+    a.inner = inner
+    # ---- with the proj_out tail: out = resid3 + (resid + FF) W3^T + b3, + GroupNorm statistics of the result (64-row panels)
+    w3 = torch.randn(c, c, generator=g) / c ** 0.5
+    b3, res3 = torch.randn(c, generator=g), torch.randn(m, c, generator=g)
+    ref3 = res3.double() + ref @ w3.double().t() + b3.double()
+    w3f, b3d, res3d = pack(w3), b3.to(DEV), res3.to(DEV)
+    a.w3_hi, a.w3_lo, a.b3 = w3f[0].data_ptr(), w3f[1].data_ptr(), b3d.data_ptr()
+    a.resid3, a.resid3_ld = res3d.data_ptr(), c
+    hw = 64 if m % 64 == 0 else 0
+    part = None
+    if hw:
+        part = torch.full((m // hw, 1, 32, 2), float("nan"), dtype=torch.float64, device=DEV)
+        a.stat_part, a.stat_cpg, a.hw_out = part.data_ptr(), c // 32, hw
+    out.fill_(float("nan"))
+    N.check(lib.wd_ff_fused(C.byref(a), _st()), "wd_ff_fused + proj_out")
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref3) < tol
+    if planes:
+        assert rel_err(unplanes(opl).cpu(), ref3) < tol
+    if part is not None:
+        o = out.cpu().double().reshape(m // hw, hw, 32, c // 32)
+        assert max_rel(part.cpu()[:, 0, :, 0], o.sum(dim=(1, 3))) < 1e-5 and max_rel(part.cpu()[:, 0, :, 1], (o * o).sum(dim=(1, 3))) < 1e-5
 
 
 @pytest.mark.parametrize("B,hh,ww,cin,n,tile,ksplit", [(3, 8, 32, 64, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 1), (4, 4, 16, 320, 320, 64320, 0),

@@ -64,7 +64,13 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
     auto issue = [&](const int slot, const int g, const int j) {  // slot, g compile-time; j run-time (uniform)
         const bool live = j < nchunk;
         const uint32_t vo = live ? lane16 : F_OOB;
-        if (g < 20) {
+        if (PROJ && g < FRING && !live) {
+            // the first groups of "chunk nchunk" are the first groups of the proj_out product (k-step 2 (g / 5) + kh, tile g % 5)
+            const uint32_t so3 = (uint32_t)(((2 * (g / 5) + kh) * (FC / 16) + 5 * cg + g % 5) * 1024);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                ring[slot][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(p ? srd3_lo : srd3_hi, lane16, so3, 0));
+        } else if (g < 20) {
             const uint32_t so = (uint32_t)(((g >> 1) * nct1 + 2 * (j * 8 + wave) + (g & 1)) * 1024);
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
@@ -207,9 +213,6 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
     e.m = a.m;
     e.n = FC;
     e.hw_out = a.hw_out > 0 ? a.hw_out : 1;
-    e.bias = a.b2;
-    e.resid = a.resid;
-    e.resid_ld = a.resid_ld;
     e.act = WD_ACT_NONE;
     e.out_f32 = a.out_f32;
     e.out_ld = a.out_ld;
@@ -217,13 +220,101 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
     e.out_lo = a.out_lo;
     e.out_pl_ld = a.out_pl_ld;
     e.ksplit = 1;
-    if (!PROJ) {
-        e.stat_part = a.stat_part;
-        e.stat_cpg = a.stat_cpg;
+    e.stat_part = a.stat_part;
+    e.stat_cpg = a.stat_cpg;
+    if constexpr (!PROJ) {
+        e.bias = a.b2;
+        e.resid = a.resid;
+        e.resid_ld = a.resid_ld;
+        wd_epilogue_from_image<FBM, FC, FNT>(e, ep, m0, 0, tid);
+    } else {
+        // ---- x' = image + b2 + x -> split-bf16 planes IN PLACE (a row's 320 floats = 1296 bytes with the pitch; its planes take
+        // 2 x 640): wave w converts rows 8 w .. 8 w + 7, every read of those rows before the first write (same wave, in order)
+        constexpr int ROWB = LDE * 4;
+        {
+            float4 v[10];
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                const int idx = it * 64 + lane, row = wave * 8 + idx / 80, c = (idx % 80) * 4;
+                const int m = m0 + row;
+                float4 x = *reinterpret_cast<const float4*>(ep + row * LDE + c);
+                if (a.b2) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.b2 + c);
+                    x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+                }
+                if (a.resid && m < a.m) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.resid + (long)m * a.resid_ld + c);
+                    x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+                }
+                v[it] = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                const int idx = it * 64 + lane, row = wave * 8 + idx / 80, c = (idx % 80) * 4;
+                uint2 hh, ll;
+                wd_split4(v[it], hh, ll);
+                char* rowp = reinterpret_cast<char*>(ep) + row * ROWB;
+                *reinterpret_cast<uint2*>(rowp + c * 2) = hh;
+                if (NPL == 2) *reinterpret_cast<uint2*>(rowp + 640 + c * 2) = ll;
+            }
+        }
+        __syncthreads();
+        // ---- out = x' Wo^T: K = 320 as ten k-steps, K-half kh takes the k-steps 2 q + kh; 25 groups through the same ring
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[i][t][r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 25; ++g) {
+            const int q = g / 5, t = g % 5;
+            if (t == 0) {
+                const int ks = 2 * q + kh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* rp = reinterpret_cast<const char*>(ep) + (i * 16 + l15) * ROWB + (ks * 4 + lq) * 16;
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) xa[i][p] = *reinterpret_cast<const bf16x8*>(rp + p * 640);
+                }
+            }
+            {
+                f32x4 col[4] = {acc2[0][t], acc2[1][t], acc2[2][t], acc2[3][t]};
+                mfma12(col, ring[g % FRING]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[i][t] = col[i];
+            }
+            if (g + FRING < 25) {
+                const int g2 = g + FRING;
+                const uint32_t so3 = (uint32_t)(((2 * (g2 / 5) + kh) * (FC / 16) + 5 * cg + g2 % 5) * 1024);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    ring[g % FRING][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(p ? srd3_lo : srd3_hi, lane16, so3, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // every fragment read of the planes is done: the image goes over them
+        for (int hh = 0; hh < 2; ++hh) {
+            if (kh == hh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 5; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* pe = ep + (i * 16 + 4 * lq + r) * LDE + cg * 80 + t * 16 + l15;
+                            *pe = (hh == 0) ? acc2[i][t][r] : *pe + acc2[i][t][r];
+                        }
+            }
+            __syncthreads();
+        }
+        e.bias = a.b3;
+        e.resid = a.resid3;
+        e.resid_ld = a.resid3_ld;
+        wd_epilogue_from_image<FBM, FC, FNT>(e, ep, m0, 0, tid);
     }
-    wd_epilogue_from_image<FBM, FC, FNT>(e, ep, m0, 0, tid);
-    (void)srd3_hi;
-    (void)srd3_lo;
 #endif
 }
 
@@ -240,7 +331,7 @@ int launch_ff(const wd_ff_args& a, hipStream_t st) {
         attr_done = true;
     }
     const int nb = (a.m + FBM - 1) / FBM;
-    const double fl = 2.0 * (double)a.m * (3.0 * (double)a.inner * FC);
+    const double fl = 2.0 * (double)a.m * (3.0 * (double)a.inner * FC + (PROJ ? (double)FC * FC : 0.0));
     WdLaunchScope scope(WD_CLS_FF, st, fl);
     hipLaunchKernelGGL((wd_ff_kernel<NPASS, PROJ>), dim3(nb), dim3(FNT), smem, st, a);
     return wd_check_launch();
@@ -262,10 +353,12 @@ extern "C" int wd_ff_fused(const wd_ff_args* pa, void* stream) {
     if ((a.out_ld | a.resid_ld | a.out_pl_ld) & 3) return WD_EINVAL;  // the vector epilogue
     if (a.resid && a.resid_ld <= 0) return WD_EINVAL;
     if ((long)a.m * a.x_ld * 2 >= 0x7FFFFFF0L || (long)2 * a.inner * a.c * 2 >= 0x7FFFFFF0L) return WD_EINVAL;
-    if (a.w3_hi) return WD_EINVAL;  // (the proj_out tail is not built yet)
+    const bool proj = a.w3_hi != nullptr;
+    if (proj && ((a.npass == 3 && !a.w3_lo) || (a.resid3 && (a.resid3_ld <= 0 || (a.resid3_ld & 3))))) return WD_EINVAL;
     if (a.stat_part && (a.stat_cpg <= 0 || FC % a.stat_cpg || a.hw_out <= 0 || !(a.hw_out % FBM == 0 || FBM % a.hw_out == 0) ||
                         (FBM > a.hw_out && FBM / a.hw_out > WD_STAT_MAXNS)))
         return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (proj) return a.npass == 3 ? launch_ff<3, true>(a, st) : launch_ff<1, true>(a, st);
     return a.npass == 3 ? launch_ff<3, false>(a, st) : launch_ff<1, false>(a, st);
 }

@@ -305,6 +305,7 @@ class UNetEngine:
         self.use_wdirect = os.environ.get("WDIFF_GEMM_WDIRECT", "1") != "0"
         # GEGLU feed-forward + residual in one launch per 64-token panel, hidden activations on chip (csrc/wd_ff.hip)
         self.fuse_ff = os.environ.get("WDIFF_FUSE_FF", "1") != "0"
+        self.fuse_proj = os.environ.get("WDIFF_FUSE_PROJ", "1") != "0"   # ... and proj_out + residual in the same launch
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
@@ -714,7 +715,7 @@ class UNetEngine:
         """Can the GEMM that produced ``s`` apply this GroupNorm in its split-K combine launch (wd_gemm_args.gn_*)?  The
         conditions of include/wdiff_hip.h, checked here so that the plan never asks for what wd_gemm would refuse."""
         pr = s.prod
-        if pr is None or not self.fuse_gn or raw is not None or self.use_conv3:
+        if pr is None or not isinstance(pr, N.WdGemmArgs) or not self.fuse_gn or raw is not None or self.use_conv3:
             return False
         if pr.out_f32 != s.t.data_ptr() or pr.out_hi or pr.gn_gamma or pr.n != s.c or not pr.stat_part or not pr.ws:
             return False
@@ -766,7 +767,8 @@ class UNetEngine:
         tab, ho, wo = self._table(x.h, x.w, mode)
         pl = self._planes(P, B * x.h * x.w, x.c)
         pr = x.prod
-        if pr is not None and self.fuse_split and not pr.out_hi and pr.out_f32 == x.t.data_ptr() and pr.n == x.c:
+        if (pr is not None and self.fuse_split and not pr.out_hi and pr.out_f32 == x.t.data_ptr() and
+                (pr.n if isinstance(pr, N.WdGemmArgs) else pr.c) == x.c):
             # the producing GEMM writes the planes beside its fp32 output (one launch and one pass over the tensor less)
             pr.out_hi, pr.out_lo = pl[0].data_ptr(), (pl[1].data_ptr() if self.npass == 3 else None)
             pr.out_pl_ld = x.c
@@ -920,6 +922,11 @@ class UNetEngine:
             ffi = tb.ff.net[2].in_features
             if self.fuse_ff and (p + ".ff1f.w") in self._w and (M + 63) // 64 >= 192:
                 # one workgroup per 64 tokens: worth it once they fill the chip (the 8 x 32 level at batch >= 48)
+                if last and self.fuse_proj and inner == c:
+                    out = self._f32(P, M, c)
+                    fa = self._ff_fused(ops, p, n3, tok2, M, inner, ffi, out, None,
+                                        proj=(name + ".po.w", self._w[name + ".po.b"], x.t, hw))
+                    return Act(out, c, h, w, fa._stats, prod=fa)
                 self._ff_fused(ops, p, n3, tok2, M, inner, ffi, None if last else tok, xpl)
             else:
                 ffh = self._planes(P, M, ffi)
@@ -941,8 +948,10 @@ class UNetEngine:
             self._pack_wf(wname, self._wf[wname], torch.cuda.current_stream(self.device).cuda_stream)
         return self._wf[wname]
 
-    def _ff_fused(self, ops, p, n3, resid, M, inner, ffi, out_f32, out_pl):
-        """x + FeedForward(LN3(x)) (unet.py:343-344, :122-149) as one wd_ff_fused launch."""
+    def _ff_fused(self, ops, p, n3, resid, M, inner, ffi, out_f32, out_pl, proj=None):
+        """x + FeedForward(LN3(x)) (unet.py:343-344, :122-149) as one wd_ff_fused launch.  proj = (weight name, bias, residual
+        tensor, hw): the SpatialTransformer's proj_out + residual (unet.py:406-412) in the same launch, with the GroupNorm statistics
+        of the result for the next ResBlock; returns the statistics tuple then."""
         a = N.WdFfArgs()
         lo_ok = self.npass == 3
         a.x_hi, a.x_lo, a.x_ld = n3[0].data_ptr(), (n3[1].data_ptr() if lo_ok else None), n3.shape[2]
@@ -956,8 +965,22 @@ class UNetEngine:
         if out_pl is not None:
             a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), (out_pl[1].data_ptr() if lo_ok else None), out_pl.shape[2]
         a.hw_out, a.npass = 1, self.npass
+        stats = None
+        if proj is not None:
+            wname, b3, x_in, hw = proj
+            w3 = self._wfrag(wname)
+            a.w3_hi, a.w3_lo, a.b3 = w3[0].data_ptr(), w3[1].data_ptr(), b3.data_ptr()
+            a.resid3, a.resid3_ld = x_in.data_ptr(), inner
+            if self.fuse_stats and inner % 32 == 0 and hw % 64 == 0:
+                nchunk = hw // 64
+                part = torch.zeros((M // hw, nchunk, 32, 2), dtype=torch.float64, device=self.device)
+                self._cur_plan.keep.append(part)
+                a.stat_part, a.stat_cpg, a.hw_out = part.data_ptr(), inner // 32, hw
+                stats = (part, nchunk, inner // 32)
         self._cur_plan.keep.append(a)
-        ops.append((self.lib.wd_ff_fused, (C.byref(a),), p + ".ff (fused)"))
+        ops.append((self.lib.wd_ff_fused, (C.byref(a),), p + (".ff + proj_out (fused)" if proj is not None else ".ff (fused)")))
+        a._stats = stats
+        return a
 
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, B: int, H: int, W: int, ctx_len: int, phosc_len: int, film_steps: int = 0) -> Plan:
