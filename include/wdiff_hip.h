@@ -118,6 +118,22 @@ typedef struct wd_gemm_args {
     float gn_eps;
     int32_t gn_silu;
     int32_t gn_cpg;
+    /* GroupNorm of the INPUT while it is staged (w_layout 3, tile 64320, npass 3 only): a32 != NULL makes src[0] the fp32 map
+     * a32 [rows][a32_ld] itself (src[0].hi / lo are ignored; c, ntaps, gather, hw_src as usual) and the rows enter the product as
+     * SiLU?((x - mean) * rstd * a32_gamma[ch] + a32_beta[ch]) (nn.GroupNorm of the consumer, unet.py:427-431 / :161-162), with
+     * the statistics of (sample, group of a32_cpg channels) summed from a32_part [batch][a32_nchunk][c / a32_pcpg][2]
+     * (wd_gn_stats' / stat_part's layout; a32_pcpg divides a32_cpg).  Zero padding stays zero.  Needs hw_out % 64 == 0 and
+     * hw_src == hw_out's sample grid (a row tile must lie inside one sample), c <= 1024, a32_ld % 4 == 0. */
+    const float* a32;
+    int32_t a32_ld;
+    const double* a32_part;
+    int32_t a32_nchunk;
+    int32_t a32_pcpg;
+    int32_t a32_cpg;
+    const float* a32_gamma;
+    const float* a32_beta;
+    float a32_eps;
+    int32_t a32_silu;
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);

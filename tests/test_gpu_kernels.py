@@ -289,6 +289,97 @@ def test_gemm_weights_to_registers_kernel(B, hh, ww, c1, c2, n, ksplit, npass, t
     assert max_rel(out.cpu(), out0.cpu()) < (5e-6 if npass == 3 else 1e-2)
 
 
+@pytest.mark.parametrize("B,hh,ww,cin,c2,n,taps,silu,eps,ksplit", [(3, 8, 32, 64, 0, 320, 9, 1, 1e-5, 1), (2, 8, 32, 320, 0, 320, 1, 0, 1e-6, 1),
+                                                                  (2, 8, 32, 128, 64, 320, 9, 1, 1e-5, 1), (5, 4, 16, 320, 0, 320, 9, 1, 1e-5, 2),
+                                                                  (64, 8, 32, 64, 0, 320, 9, 1, 1e-5, 1)])
+def test_gemm_groupnorm_of_the_input_while_staging(B, hh, ww, cin, c2, n, taps, silu, eps, ksplit):
+    """wd_gemm_args.a32*: src[0] is the fp32 map and the consumer's GroupNorm (+ SiLU) is applied while the weights-to-registers
+    kernel stages its rows - vs F.group_norm -> SiLU -> conv in fp64 (zero padding applies to the NORMALISED map), and vs the
+    two-launch form (wd_gn_apply planes -> wd_gemm); 3x3 and 1x1, an identity skip source from planes beside it, K cut."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B + cin + taps + c2)
+    hw, m = hh * ww, B * hh * ww
+    x = torch.randn(m, cin, generator=g) * 1.5 + 0.3
+    gam, bet = torch.randn(cin, generator=g) * 0.3 + 1, torch.randn(cin, generator=g) * 0.2
+    w = torch.randn(n, taps * cin + c2, generator=g) / (taps * cin + c2) ** 0.5
+    bias = torch.randn(n, generator=g)
+    xn = F.group_norm(x.double().reshape(B, hw, cin).permute(0, 2, 1), 32, gam.double(), bet.double(), eps)
+    if silu:
+        xn = F.silu(xn)
+    if taps == 9:
+        ref = F.conv2d(xn.reshape(B, cin, hh, ww), w[:, :9 * cin].reshape(n, 3, 3, cin).permute(0, 3, 1, 2).double(), padding=1)
+        ref = ref.permute(0, 2, 3, 1).reshape(m, n)
+    else:
+        ref = xn.permute(0, 2, 1).reshape(m, cin) @ w[:, :cin].double().t()
+    ref = ref + bias.double()
+    xd = x.to(DEV)
+    cpg = cin // 32
+    nchunk = lib.wd_gn_nchunk(hw)
+    part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+    N.check(lib.wd_gn_stats(xd.data_ptr(), cin, B, hw, cin, cpg, part.data_ptr(), _st()), "stats")
+    tab, _, _ = conv_gather_table(hh, ww, "same")
+    tabd = torch.from_numpy(tab).to(DEV) if taps == 9 else None
+    a = N.WdGemmArgs()
+    s0 = N.WdSrc()
+    s0.gather = tabd.data_ptr() if tabd is not None else None
+    s0.ld, s0.c, s0.ntaps, s0.hw_src = cin, cin, taps, hw
+    a.src[0] = s0
+    a.nsrc = 1
+    keep = []
+    if c2:
+        a2 = torch.randn(m, c2, generator=g)
+        ref = ref + a2.double() @ w[:, taps * cin:].double().t()
+        p2 = planes_of(a2.to(DEV))
+        keep.append(p2)
+        s1 = N.WdSrc()
+        s1.hi, s1.lo, s1.ld, s1.c, s1.ntaps = p2[0].data_ptr(), p2[1].data_ptr(), c2, c2, 1
+        a.src[1] = s1
+        a.nsrc = 2
+    a.npass = 3
+    wp = planes_of(w.to(DEV))
+    wf = torch.empty_like(wp)
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), n, w.shape[1], wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    a.w_hi, a.w_lo, a.w_layout, a.tile = wf[0].data_ptr(), wf[1].data_ptr(), 3, 64320
+    a.slab_rows = ww if taps == 9 else 0
+    a.m, a.n, a.ktot, a.hw_out = m, n, w.shape[1], hw
+    bd, gd, btd = bias.to(DEV), gam.to(DEV), bet.to(DEV)
+    a.bias = bd.data_ptr()
+    out = torch.full((m, n), float("nan"), device=DEV)
+    a.out_f32, a.out_ld = out.data_ptr(), n
+    a.a32, a.a32_ld, a.a32_part = xd.data_ptr(), cin, part.data_ptr()
+    a.a32_nchunk, a.a32_pcpg, a.a32_cpg = nchunk, cpg, cpg
+    a.a32_gamma, a.a32_beta, a.a32_eps, a.a32_silu = gd.data_ptr(), btd.data_ptr(), eps, silu
+    ws = torch.empty(4 * m * n, device=DEV)
+    a.ksplit = ksplit
+    if ksplit != 1:
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm + input GroupNorm")
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 3e-5
+    first = out.clone()
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm + input GroupNorm")
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    # the two-launch form: wd_gn_apply writes the normalised planes, the same kernel multiplies them
+    pl = torch.zeros(2, m, cin, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.wd_gn_apply(xd.data_ptr(), cin, B, hw, cin, cpg, part.data_ptr(), nchunk, cpg, gd.data_ptr(), btd.data_ptr(), eps, silu,
+                            pl[0].data_ptr(), pl[1].data_ptr(), cin, 0, None, None, _st()), "apply")
+    a.a32 = None
+    s0.hi, s0.lo = pl[0].data_ptr(), pl[1].data_ptr()
+    a.src[0] = s0
+    out2 = torch.full((m, n), float("nan"), device=DEV)
+    a.out_f32 = out2.data_ptr()
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm over planes")
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), out2.cpu()) < 2e-5
+    # refused where a tile would straddle samples, or without the fragment-major layout
+    a.a32 = xd.data_ptr()
+    a.hw_out = 100
+    assert lib.wd_gemm(C.byref(a), _st()) != 0
+    a.hw_out, a.w_layout = hw, 0
+    assert lib.wd_gemm(C.byref(a), _st()) != 0
+
+
 @pytest.mark.parametrize("m,inner,npass,planes", [(64, 1280, 3, True), (200, 1280, 3, False), (4096, 1280, 3, True), (130, 256, 1, True)])
 def test_fused_geglu_feed_forward(m, inner, npass, planes):
     """wd_ff_fused: x + GEGLU(LN(x) W1^T + b1) W2^T + b2 (unet.py:122-149, 343-344) in one launch - hidden activations never

@@ -39,7 +39,9 @@ class WdGemmArgs(C.Structure):
                 ("w_layout", C.c_int32), ("slab_rows", C.c_int32), ("ksplit", C.c_int32), ("ws", _vp),
                 ("ws_floats", C.c_int64), ("stat_part", _vp), ("stat_cpg", C.c_int32), ("dbg", C.c_int32),
                 ("tickets", _vp), ("ntickets", C.c_int32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_eps", C.c_float),
-                ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32)]
+                ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32), ("a32", _vp), ("a32_ld", C.c_int32), ("a32_part", _vp),
+                ("a32_nchunk", C.c_int32), ("a32_pcpg", C.c_int32), ("a32_cpg", C.c_int32), ("a32_gamma", _vp), ("a32_beta", _vp),
+                ("a32_eps", C.c_float), ("a32_silu", C.c_int32)]
 
 
 class WdFfArgs(C.Structure):

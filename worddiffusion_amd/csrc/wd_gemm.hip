@@ -2217,7 +2217,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.w_layout == 3) {
         // fragment-major weights (wd_gemm_pack_w): the 64 x 320 weights-to-registers kernel only
         if (a.n % 160 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160) || a.ktot % 64) return WD_EINVAL;
-        if (a.tile == 0) a.tile = 128160;
+        if (a.tile == 0) a.tile = a.a32 ? 64320 : 128160;
         if (a.n % (a.tile % 1000)) return WD_EINVAL;
     }
     if (a.stat_part) {
@@ -2254,7 +2254,13 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     long k = 0;
     for (int s = 0; s < a.nsrc; ++s) {
         const wd_src& q = a.src[s];
-        if (!q.hi || (a.npass == 3 && !q.lo)) return WD_EINVAL;
+        if (s == 0 && a.a32) {
+            // src[0] staged from the fp32 map with the consumer's GroupNorm: the weights-to-registers kernel, 64-row tiles inside one sample
+            if (a.w_layout != 3 || a.npass != 3 || (a.tile && a.tile != 64320) || a.n % 320 || a.hw_out % 64 || !a.a32_part || !a.a32_gamma ||
+                !a.a32_beta || a.a32_nchunk <= 0 || a.a32_pcpg <= 0 || a.a32_cpg <= 0 || a.a32_cpg % a.a32_pcpg || q.c % a.a32_cpg ||
+                q.c > 1024 || a.a32_ld < q.c || (a.a32_ld & 3) || (reinterpret_cast<uintptr_t>(a.a32) & 15) || q.hw_src <= 0)
+                return WD_EINVAL;
+        } else if (!q.hi || (a.npass == 3 && !q.lo)) return WD_EINVAL;
         if (q.c <= 0 || q.c % BK || q.ld % 8 || q.ntaps < 1) return WD_EINVAL;
         if (!q.gather && q.ntaps != 1) return WD_EINVAL;
         if (q.gather && q.hw_src <= 0) return WD_EINVAL;
@@ -2267,7 +2273,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         for (int s = 0; s < a.nsrc; ++s) {
             const wd_src& q = a.src[s];
             const long rows = q.gather ? (long)((a.m + a.hw_out - 1) / a.hw_out) * q.hw_src : (long)a.m;
-            if (rows * q.ld * 2 >= lim) return WD_EINVAL;
+            if ((s == 0 && a.a32) ? rows * a.a32_ld * 4 >= lim : rows * q.ld * 2 >= lim) return WD_EINVAL;
         }
     }
     if (a.act == WD_ACT_GEGLU && (a.n % 64 || a.tile == 0)) return WD_EINVAL;  // the tile fixes the x|gate packing

@@ -33,7 +33,12 @@ __device__ __forceinline__ int w_lds_off(int row, int ch) { return row * 128 + (
 // RH = 2: tile 128 x 160, waves = 2 K-halves x 2 row halves x 2 column groups of 80: the two row halves of a column group ask for
 //         the same W kilobytes within a few hundred cycles of one another (the second request is served by the CU's L1), so a
 //         64-deep stage pulls 32 KB of A + 40 KB of W from L2 instead of 16 + 80.
-template <int NPASS, int RH>
+// A32: src[0] is an fp32 map and the consumer's GroupNorm (+ SiLU) is applied while its rows are staged (wd_gemm_args.a32*): the
+//      thread that moves eight channels of a row loads them as two float4 instead of two bf16x8 planes - the same 32 bytes -
+//      and normalises, activates and splits them between the load (issued a stage earlier) and the ds_write; the
+//      wd_gn_apply launch, its pass over the tensor and the planes it wrote disappear.  A tile's rows are one sample
+//      (hw_out % BM == 0): its 2 c scale / shift values are derived from the statistics partials once per workgroup.
+template <int NPASS, int RH, bool A32>
 __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, const int nbn, const int nbm) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
@@ -94,6 +99,30 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             s_tab[idx] = v;
         }
     }
+    float* s_aff = reinterpret_cast<float*>(s_tab + 9 * BM);  // A32: [c][2] (scale, shift) of this tile's sample
+    if constexpr (A32) {
+        const int c0 = a.src[0].c;
+        const int b = m0 / a.hw_out;   // (hw_out % BM == 0: one sample per tile)
+        const int ngp = c0 / a.a32_pcpg, ratio = a.a32_cpg / a.a32_pcpg;
+        for (int c = tid; c < c0; c += WNT) {
+            const int g = c / a.a32_cpg;
+            double su = 0.0, sq = 0.0;
+            for (int k = 0; k < ratio; ++k)
+                for (int ck = 0; ck < a.a32_nchunk; ++ck) {
+                    const double* pp = a.a32_part + (((long)b * a.a32_nchunk + ck) * ngp + g * ratio + k) * 2;
+                    su += pp[0];
+                    sq += pp[1];
+                }
+            const double n = (double)a.src[0].hw_src * a.a32_cpg;
+            const double mu = su / n;
+            double var = sq / n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)a.a32_eps));
+            const float sc = rstd * a.a32_gamma[c];
+            s_aff[2 * c] = sc;
+            s_aff[2 * c + 1] = a.a32_beta[c] - (float)mu * sc;
+        }
+    }
     __syncthreads();
 
     auto make_srd = [](const wd_bf16* p) {
@@ -133,7 +162,8 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
     }
     // (both sources' descriptors are loop constants chosen by a uniform branch at the load: a descriptor REASSIGNED inside the
     // loop ends up in VGPRs and turns every load into a waterfall loop)
-    const __amdgpu_buffer_rsrc_t srd0_hi = make_srd(a.src[0].hi), srd0_lo = make_srd(a.src[0].lo ? a.src[0].lo : a.src[0].hi);
+    const __amdgpu_buffer_rsrc_t srd0_hi = make_srd(A32 ? reinterpret_cast<const wd_bf16*>(a.a32) : a.src[0].hi),
+                                 srd0_lo = make_srd(A32 ? reinterpret_cast<const wd_bf16*>(a.a32) : (a.src[0].lo ? a.src[0].lo : a.src[0].hi));
     const wd_bf16* p1h = a.nsrc > 1 ? a.src[1].hi : a.src[0].hi;
     const wd_bf16* p1l = a.nsrc > 1 ? (a.src[1].lo ? a.src[1].lo : a.src[1].hi) : p1h;
     const __amdgpu_buffer_rsrc_t srd1_hi = make_srd(p1h), srd1_lo = make_srd(p1l);
@@ -145,7 +175,8 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             int r;
             if (s == 0) r = s_tab[tap * BM + row];
             else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
-            a_voff[j] = r >= 0 ? (uint32_t)r * (uint32_t)(cur_ld * 2) + (uint32_t)(ach * 16) : WD_OOB;
+            if (A32 && s == 0) a_voff[j] = r >= 0 ? (uint32_t)r * (uint32_t)(a.a32_ld * 4) + (uint32_t)(ach * 32) : WD_OOB;
+            else a_voff[j] = r >= 0 ? (uint32_t)r * (uint32_t)(cur_ld * 2) + (uint32_t)(ach * 16) : WD_OOB;
         }
     };
     locate();
@@ -177,23 +208,57 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
     // out-of-range offset (the buffer range check returns zeros without touching memory) instead of being branched around: the
     // compiler's vmcnt bookkeeping merges the two sides of such a branch to the more conservative count, which made every
     // stage wait for the loads it had just issued.
-    w_u32x4 ra[RH][NPL];  // the A chunks of the stage after next, on their way to LDS
+    w_u32x4 ra[RH][NPL];  // the A chunks of the stage after next, on their way to LDS (A32: the eight fp32 values, raw)
+    int ra_ch = 0;        // A32: first channel of the chunk in ra, or -1 when ra holds planes of src[1]
+    bool ra_ok[RH];       // A32: the row is a real one (zero padding stays zero AFTER the normalisation)
     auto load_a = [&](const bool live) {
+        if (A32) ra_ch = (s == 0) ? kc * 64 + ach * 8 : -1;
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             const uint32_t vo = live ? a_voff[j] : WD_OOB;
+            if (A32) ra_ok[j] = vo != WD_OOB;
+            if (A32 && s == 0) {
+                static_assert(!A32 || NPL == 2, "the fp32 source path holds eight floats in the two plane registers");
+                ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(srd0_hi, vo, kc * 256, 0);
+                ra[j][NPL - 1] = __builtin_amdgcn_raw_buffer_load_b128(srd0_hi, vo + 16, kc * 256, 0);
+            } else {
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                if (s == 0) ra[j][p] = __builtin_amdgcn_raw_buffer_load_b128(p ? srd0_lo : srd0_hi, vo, kc * 128, 0);
-                else ra[j][p] = __builtin_amdgcn_raw_buffer_load_b128(p ? srd1_lo : srd1_hi, vo, kc * 128, 0);
+                for (int p = 0; p < NPL; ++p) {
+                    if (s == 0) ra[j][p] = __builtin_amdgcn_raw_buffer_load_b128(p ? srd0_lo : srd0_hi, vo, kc * 128, 0);
+                    else ra[j][p] = __builtin_amdgcn_raw_buffer_load_b128(p ? srd1_lo : srd1_hi, vo, kc * 128, 0);
+                }
             }
         }
     };
     auto store_a = [&](char* base) {
+        if (A32 && ra_ch >= 0) {
+            // y = x * scale + shift (GroupNorm with its affine folded per (sample, channel)), SiLU, split into the two planes
+            const float4* tab = reinterpret_cast<const float4*>(s_aff + 2 * ra_ch);  // (sc0 sh0 sc1 sh1) ...
+            const float4 t0 = tab[0], t1 = tab[1], t2 = tab[2], t3 = tab[3];
+            const bool silu = a.a32_silu != 0;
 #pragma unroll
-        for (int j = 0; j < RH; ++j)
+            for (int j = 0; j < RH; ++j) {
+                const float4 x0 = __builtin_bit_cast(float4, ra[j][0]), x1 = __builtin_bit_cast(float4, ra[j][NPL - 1]);
+                float4 y0, y1;
+                y0.x = x0.x * t0.x + t0.y; y0.y = x0.y * t0.z + t0.w; y0.z = x0.z * t1.x + t1.y; y0.w = x0.w * t1.z + t1.w;
+                y1.x = x1.x * t2.x + t2.y; y1.y = x1.y * t2.z + t2.w; y1.z = x1.z * t3.x + t3.y; y1.w = x1.w * t3.z + t3.w;
+                if (silu) {
+                    y0.x = wd_silu(y0.x); y0.y = wd_silu(y0.y); y0.z = wd_silu(y0.z); y0.w = wd_silu(y0.w);
+                    y1.x = wd_silu(y1.x); y1.y = wd_silu(y1.y); y1.z = wd_silu(y1.z); y1.w = wd_silu(y1.w);
+                }
+                if (!ra_ok[j]) y0 = y1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 h0, l0, h1, l1;
+                wd_split4(y0, h0, l0);
+                wd_split4(y1, h1, l1);
+                *reinterpret_cast<w_u32x4*>(base + j * 8192 + a_dst) = w_u32x4{h0.x, h0.y, h1.x, h1.y};
+                *reinterpret_cast<w_u32x4*>(base + (NPL - 1) * A_PL + j * 8192 + a_dst) = w_u32x4{l0.x, l0.y, l1.x, l1.y};
+            }
+        } else {
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<w_u32x4*>(base + p * A_PL + j * 8192 + a_dst) = ra[j][p];
+            for (int j = 0; j < RH; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<w_u32x4*>(base + p * A_PL + j * 8192 + a_dst) = ra[j][p];
+        }
     };
     auto load_b = [&](bf16x8 (&fb)[5][NPL], const bool live) {
         const uint32_t so = live ? (uint32_t)(2 * kb + kh) * kstep_bytes : 0u;
@@ -359,16 +424,16 @@ __global__ void __launch_bounds__(256) wd_pack_w_kernel(const wd_bf16* __restric
     if (lo) reinterpret_cast<uint4*>(out_lo)[i] = *reinterpret_cast<const uint4*>(lo + src);
 }
 
-template <int NPASS, int RH>
+template <int NPASS, int RH, bool A32 = false>
 int launchw(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int BM = 64 * RH, BN = 320 / RH;
-    constexpr int loop_smem = 2 * NPL * BM * 128 + 9 * BM * 4;
+    constexpr int loop_smem = 2 * NPL * BM * 128 + 9 * BM * 4 + (A32 ? 2 * 1024 * 4 : 0);  // (+ the scale / shift table: c <= 1024)
     constexpr int red_smem = BM * (BN + 4) * 4 + WD_STAT_SCRATCH;
     constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemmw_kernel<NPASS, RH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemmw_kernel<NPASS, RH, A32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 smem) != hipSuccess)
             return WD_ELAUNCH;
         attr_done = true;
@@ -376,7 +441,7 @@ int launchw(const wd_gemm_args& a, hipStream_t st) {
     const int nbn = a.n / BN, nbm = (a.m + BM - 1) / BM;
     {
         WdLaunchScope scope(WD_CLS_GEMM_WDIRECT, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
-        hipLaunchKernelGGL((wd_gemmw_kernel<NPASS, RH>), dim3(nbn * nbm * a.ksplit), dim3(WNT), smem, st, a, nbn, nbm);
+        hipLaunchKernelGGL((wd_gemmw_kernel<NPASS, RH, A32>), dim3(nbn * nbm * a.ksplit), dim3(WNT), smem, st, a, nbn, nbm);
     }
     if (a.ksplit > 1) return wd_gemm_launch_reduce(a, st, BM);
     return wd_check_launch();
@@ -385,6 +450,7 @@ int launchw(const wd_gemm_args& a, hipStream_t st) {
 }  // namespace
 
 int wd_gemmw_launch(const wd_gemm_args& a, hipStream_t st) {
+    if (a.a32) return launchw<3, 1, true>(a, st);  // (wd_gemm checked: npass 3, tile 64320, one sample per tile)
     if (a.tile == 128160) return a.npass == 3 ? launchw<3, 2>(a, st) : launchw<1, 2>(a, st);
     return a.npass == 3 ? launchw<3, 1>(a, st) : launchw<1, 1>(a, st);
 }

@@ -306,6 +306,9 @@ class UNetEngine:
         # GEGLU feed-forward + residual in one launch per 64-token panel, hidden activations on chip (csrc/wd_ff.hip)
         self.fuse_ff = os.environ.get("WDIFF_FUSE_FF", "1") != "0"
         self.fuse_proj = os.environ.get("WDIFF_FUSE_PROJ", "1") != "0"   # ... and proj_out + residual in the same launch
+        # GroupNorm (+ SiLU) of a convolution's input applied while the weights-to-registers kernel stages its rows (no wd_gn_apply
+        # launch, no operand planes of the normalised map)
+        self.fuse_gn_in = int(os.environ.get("WDIFF_FUSE_GN_IN", "1"))  # 0 off, 1 the 1x1 consumers, 2 the 3x3 consumers too
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
@@ -553,7 +556,8 @@ class UNetEngine:
 
     def _gemm(self, ops, what, srcs, wname, m, hw_out, bias=None, rowvec=None, rowvec_ld=0, resid=None,
               resid_ld=0, resid_rows=None, act=N.ACT_NONE, out_f32=None, out_ld=0, out_pl=None, n=None, tile=0,
-              w_row_off=0, want_stats=False):
+              w_row_off=0, want_stats=False, a32=None):
+        """a32 = (Act, norm name, eps, silu): src[0] is that fp32 map, normalised while it is staged (wd_gemm_args.a32*)."""
         a = N.WdGemmArgs()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -576,6 +580,14 @@ class UNetEngine:
                    # (the K-cut layers of the 4 x 16 level stay on the LDS-staged kernel: this one is 5 % faster on their long loops
                    # in isolation and 2 % slower inside the step)
                    ((m + 63) // 64) * (nrows // 320) >= 256)
+        assert a32 is None or wdirect, what
+        if a32 is not None:
+            x32, gname, eps, silu = a32
+            part, nchunk, pc = x32.stats
+            a.a32, a.a32_ld, a.a32_part = x32.t.data_ptr(), x32.c, part.data_ptr()
+            a.a32_nchunk, a.a32_pcpg, a.a32_cpg = nchunk, pc, x32.c // 32
+            a.a32_gamma, a.a32_beta = self._w[gname + ".g"].data_ptr(), self._w[gname + ".b"].data_ptr()
+            a.a32_eps, a.a32_silu = float(eps), int(silu)
         if wdirect:
             wf = self._wfrag(wname)
             a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
@@ -711,6 +723,37 @@ class UNetEngine:
                              int(silu), pl[0].data_ptr(), lo, ctot, c0, rhi, rlo), what + ":apply"))
         return pl, raw
 
+    def _gn_in_consumer(self, P, ops, what, srcs: List[Act], want_raw, M, hw, ncols, taps=1) -> bool:
+        """Can the convolution that consumes this GroupNorm apply it itself (wd_gemm_args.a32*)?  One fp32 source with known (or
+        computable) statistics, a consumer that takes the 64 x 320 weights-to-registers kernel, tiles inside one sample.
+        Measured at B = 64: a 1x1 consumer (proj_in: five stages, no SiLU) loses nothing and saves the wd_gn_apply launch; a 3x3
+        consumer normalises and activates every element nine times (once per tap) and runs ~30 us longer per launch than the
+        10 us launch it saves (step 2.095 -> 2.137 ms with all of them on) - WDIFF_FUSE_GN_IN=2 switches those on anyway."""
+        if not (self.fuse_gn_in and self.use_wdirect and self.npass == 3 and len(srcs) == 1 and not want_raw and not self.use_conv3):
+            return False
+        if taps > 1 and self.fuse_gn_in < 2:
+            return False
+        s = srcs[0]
+        if s.c % 64 or s.c > 1024 or hw % 64 or ncols % 320 or ((M + 63) // 64) * (ncols // 320) < 256:
+            return False
+        if s.stats is None:  # no producer-side statistics: one pass over the tensor
+            nchunk = self.lib.wd_gn_nchunk(hw)
+            pc = s.c // 32
+            part = torch.empty((self._B, nchunk, 32, 2), dtype=torch.float64, device=self.device)
+            P.keep.append(part)
+            ops.append((self.lib.wd_gn_stats, (s.t.data_ptr(), s.c, self._B, hw, s.c, pc, part.data_ptr()), what + ":stats"))
+            s.stats = (part, nchunk, pc)
+        return (s.c // 32) % s.stats[2] == 0
+
+    def _src32(self, x: Act, ntaps=1, gather=None, hw_src=0) -> N.WdSrc:
+        """src[0] of a GEMM that reads the fp32 map itself (a32): channel count, taps and gather table only."""
+        s = N.WdSrc()
+        s._tab_np = self._tab_np.get(gather.data_ptr()) if gather is not None else None
+        s._same_w = self._same_w.get(gather.data_ptr(), 0) if gather is not None else 0
+        s.hi, s.lo, s.gather = None, None, _ptr(gather)
+        s.ld, s.c, s.ntaps, s.hw_src = x.c, x.c, ntaps, hw_src
+        return s
+
     def _gn_in_combine(self, s: Act, raw, hw, cpg, pc, nchunk, coff) -> bool:
         """Can the GEMM that produced ``s`` apply this GroupNorm in its split-K combine launch (wd_gemm_args.gn_*)?  The
         conditions of include/wdiff_hip.h, checked here so that the plan never asks for what wd_gemm would refuse."""
@@ -744,21 +787,31 @@ class UNetEngine:
         assert cin == sum(s.c for s in srcs)
         tab, _, _ = self._table(h, w, "same")
         need_raw = cin != cout
-        a1, raw = self._gn(P, ops, name + ".gn1", srcs, name + ".gn1", 1e-5, True, want_raw=need_raw)
         h1 = self._f32(P, M, cout)
-        g1 = self._gemm(ops, name + ".conv1", [self._src(a1, cin, 9, tab, hw)], name + ".c1.w", M, hw,
+        if self._gn_in_consumer(P, ops, name + ".gn1", srcs, need_raw, M, hw, cout, taps=9):
+            s1, in1 = self._src32(srcs[0], 9, tab, hw), (srcs[0], name + ".gn1", 1e-5, True)
+            raw = None
+        else:
+            a1, raw = self._gn(P, ops, name + ".gn1", srcs, name + ".gn1", 1e-5, True, want_raw=need_raw)
+            s1, in1 = self._src(a1, cin, 9, tab, hw), None
+        g1 = self._gemm(ops, name + ".conv1", [s1], name + ".c1.w", M, hw,
                         bias=self._w[name + ".c1.b"], rowvec=self._film.data_ptr() + 4 * self.film_off[name],
-                        rowvec_ld=self.film_total, out_f32=h1, out_ld=cout, want_stats=True)
-        a2, _ = self._gn(P, ops, name + ".gn2", [Act(h1, cout, h, w, g1._stats, prod=g1)], name + ".gn2", 1e-5, True)
+                        rowvec_ld=self.film_total, out_f32=h1, out_ld=cout, want_stats=True, a32=in1)
+        h1a = Act(h1, cout, h, w, g1._stats, prod=g1)
+        if self._gn_in_consumer(P, ops, name + ".gn2", [h1a], False, M, hw, cout, taps=9):
+            s2, in2 = self._src32(h1a, 9, tab, hw), (h1a, name + ".gn2", 1e-5, True)
+        else:
+            a2, _ = self._gn(P, ops, name + ".gn2", [h1a], name + ".gn2", 1e-5, True)
+            s2, in2 = self._src(a2, cout, 9, tab, hw), None
         out = self._f32(P, M, cout)
         if need_raw:
-            g2 = self._gemm(ops, name + ".conv2+skip", [self._src(a2, cout, 9, tab, hw), self._src(raw, cin)],
+            g2 = self._gemm(ops, name + ".conv2+skip", [s2, self._src(raw, cin)],
                             name + ".c2.w", M, hw, bias=self._w[name + ".c2.b"], out_f32=out, out_ld=cout,
-                            want_stats=True)
+                            want_stats=True, a32=in2)
         else:
-            g2 = self._gemm(ops, name + ".conv2", [self._src(a2, cout, 9, tab, hw)], name + ".c2.w", M, hw,
+            g2 = self._gemm(ops, name + ".conv2", [s2], name + ".c2.w", M, hw,
                             bias=self._w[name + ".c2.b"], resid=srcs[0].t.data_ptr(), resid_ld=cout, out_f32=out,
-                            out_ld=cout, want_stats=True)
+                            out_ld=cout, want_stats=True, a32=in2)
         return Act(out, cout, h, w, g2._stats, prod=g2)
 
     def _resample(self, P, name, mod, x: Act, mode: str, tile: int = 0) -> Act:
@@ -798,10 +851,14 @@ class UNetEngine:
         heads, d = mod.heads, mod.d_head
         inner = heads * d
         L = self._ctx_len
-        g, _ = self._gn(P, ops, name + ".gn", [x], name + ".gn", 1e-6, False)
         tok = self._f32(P, M, inner)
-        self._gemm(ops, name + ".proj_in", [self._src(g, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
-                   out_f32=tok, out_ld=inner)
+        if self._gn_in_consumer(P, ops, name + ".gn", [x], False, M, hw, inner):
+            self._gemm(ops, name + ".proj_in", [self._src32(x, hw_src=hw)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
+                       out_f32=tok, out_ld=inner, a32=(x, name + ".gn", 1e-6, False))
+        else:
+            g, _ = self._gn(P, ops, name + ".gn", [x], name + ".gn", 1e-6, False)
+            self._gemm(ops, name + ".proj_in", [self._src(g, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
+                       out_f32=tok, out_ld=inner)
         xpl = None
         fuse = self.fuse_xattn and bool(self.lib.wd_xattn_supported(inner, heads, L))
 
