@@ -399,11 +399,15 @@ def launch_check(a):
     if world > 1:
         dist.barrier()
     slowest = wdist.max_over_ranks(float(rank + 1))
-    if rank == 0:
-        print(json.dumps(dict(launch_check=True, n_gpus=world, max_over_ranks=slowest, value=None,
-                              note="control-flow rehearsal only: no kernel ran")))
+    train = None
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+        if a.train_steps != 0:  # the multi-GPU training leg's process handling (fresh children, wall-clock limit), without kernels
+            train = train_leg_in_children(a, rank, world, local)
+    if rank == 0:
+        print(json.dumps(dict(launch_check=True, n_gpus=world, max_over_ranks=slowest, value=None, train_step=train,
+                              note="control-flow rehearsal only: no kernel ran")))
 
 
 def full_call_leg(model, args, dev, B, rank, world, barrier, wdist):
@@ -525,6 +529,66 @@ def roofline_leg(runner, precision):
 
 
 
+def train_worker(a):
+    """Child process of one rank for the multi-GPU training leg (``--train-worker``): its own process group on MASTER_PORT (the
+    parent passes port + 1), ``train_leg`` with a barrier either side, rank 0 prints the object."""
+    from worddiffusion_amd import dist as wdist
+    if os.environ.get("WDIFF_BENCH_TEST_HANG") == "1":  # (tests/test_dist_gloo.py: the timeout path)
+        time.sleep(3600)
+    if a.launch_check:  # CPU rehearsal of the control flow: rendezvous, barrier, one object - no kernel
+        rank, world, local = wdist.init_process_group("gloo")
+        import torch.distributed as dist
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps(dict(launch_check=True, n_gpus=world, ms_per_step=None)))
+        dist.destroy_process_group()
+        return
+    rehearse = os.environ.get("WDIFF_BENCH_REHEARSE", "0") == "1"
+    rank, world, local = wdist.init_process_group("gloo" if rehearse else "nccl")
+    if rehearse:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    def barrier():
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    out = train_leg(dev, a.precision, a.batch, a.train_steps, 3, rank, world, barrier, wdist)
+    if rank == 0:
+        print(json.dumps(out))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def train_leg_in_children(a, rank, world, local):
+    """Every rank starts its own child (same RANK / WORLD_SIZE, MASTER_PORT + 1) and waits for it with a wall-clock limit; rank
+    0 returns the child's object, or ``{"error": ...}``.  The children are new processes (subprocess, no exec of this one)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-worker", "--gpus", str(world), "--batch", str(a.batch),
+           "--precision", a.precision, "--train-steps", str(a.train_steps)] + (["--launch-check"] if a.launch_check else [])
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        out, _ = p.communicate(timeout=a.train_timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return dict(error="timeout", limit_s=a.train_timeout)
+    if rank != 0:
+        return None
+    if p.returncode != 0:
+        return dict(error=f"child exit code {p.returncode}")
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    try:
+        return json.loads(lines[-1])
+    except (IndexError, ValueError):
+        return dict(error="no JSON object from the training child")
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -544,6 +608,10 @@ def main():
                          "training leg with its gradient all-reduce)")
     ap.add_argument("--no-full-call", action="store_true", help="skip the un-extrapolated full sampling() call")
     ap.add_argument("--no-phosc", action="store_true", help="skip the PHOSC-variant extra (BASELINE configs[4] on one GPU)")
+    ap.add_argument("--train-worker", action="store_true",
+                    help="(internal) this process is the per-rank child of the multi-GPU training leg: rendezvous, train_leg, one JSON "
+                         "object from rank 0")
+    ap.add_argument("--train-timeout", type=float, default=240.0, help="wall-clock limit of the multi-GPU training leg (seconds)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous / barrier / max-over-ranks only, no GPU work (CPU rehearsal of the N-rank control flow)")
     a = ap.parse_args()
@@ -554,6 +622,8 @@ def main():
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     if env_world is not None and int(env_world) != a.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={env_world} but --gpus {a.gpus}")
+    if a.train_worker:
+        return train_worker(a)
     if a.launch_check:
         return launch_check(a)
 
@@ -635,8 +705,18 @@ def main():
 
     train = None
     if a.train_steps < 0:
-        a.train_steps = 30 if world == 1 else 0
-    if a.train_steps > 0 and a.variant == "base":
+        a.train_steps = 30 if world == 1 else 10
+    if a.train_steps > 0 and a.variant == "base" and world > 1:
+        # BASELINE configs[3] (data-parallel training over RCCL): every rank hands the leg to a FRESH child process with a wall-clock
+        # limit - its rendezvous, its collectives and its GPU context are its own, so a stuck all-reduce costs `train_step:
+        # {"error": "timeout"}` and never the headline line, which is already measured
+        del runner
+        torch.cuda.empty_cache()
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        train = train_leg_in_children(a, rank, world, local)
+    elif a.train_steps > 0 and a.variant == "base":
         del runner
         torch.cuda.empty_cache()
         try:
@@ -677,7 +757,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

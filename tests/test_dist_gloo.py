@@ -104,6 +104,15 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["launch_check"] is True and line["max_over_ranks"] == 2.0
+    # the multi-GPU training leg (BASELINE configs[3]) runs in fresh per-rank children with a wall-clock limit: the rehearsal
+    # children rendezvous on their own port and rank 0's object is merged into the line ...
+    assert line["train_step"] == {"launch_check": True, "n_gpus": 2, "ms_per_step": None}
+    # ... and children that hang cost `train_step: {"error": "timeout"}`, not the line
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--train-timeout", "3"],
+                       env=dict(env, WDIFF_BENCH_TEST_HANG="1"), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["train_step"]["error"] == "timeout"
     # under a launcher whose world size disagrees with --gpus the script refuses instead of printing a wrong n_gpus
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
                        env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=60)
