@@ -134,6 +134,12 @@ typedef struct wd_gemm_args {
     const float* a32_beta;
     float a32_eps;
     int32_t a32_silu;
+    /* LayerNorm of the RESULT's rows in the epilogue (w_layout 3, tile 64320, n == 320, no K cut): ln_gamma != NULL makes
+     * out_hi / out_lo receive LayerNorm(result row) * ln_gamma + ln_beta (nn.LayerNorm of the consuming transformer block,
+     * unetPhosc.py:241-246 norm1 / norm2 / norm3) instead of the result's own planes; out_f32 is still the result. */
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);

@@ -380,6 +380,48 @@ def test_gemm_groupnorm_of_the_input_while_staging(B, hh, ww, cin, c2, n, taps, 
     assert lib.wd_gemm(C.byref(a), _st()) != 0
 
 
+@pytest.mark.parametrize("m,k,resid", [(200, 320, True), (4096, 640, False), (64, 64, True)])
+def test_gemm_layernorm_of_the_result_rows(m, k, resid):
+    """wd_gemm_args.ln_*: the 64 x 320 weights-to-registers tiles hold whole rows, so the epilogue emits LayerNorm(result) * gamma +
+    beta as the operand planes of the next GEMM (fp32 result still written) - vs F.layer_norm of the fp64 result; refused where
+    rows are not whole (n != 320, K cut, LDS-staged layout)."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(m + k)
+    n = 320
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    bias, res = torch.randn(n, generator=g), torch.randn(m, n, generator=g)
+    gam, bet = torch.randn(n, generator=g) * 0.3 + 1, torch.randn(n, generator=g) * 0.2
+    ref = x.double() @ w.double().t() + bias.double() + (res.double() if resid else 0)
+    refn = F.layer_norm(ref, (n,), gam.double(), bet.double(), 1e-5)
+    xp, wp = planes_of(x.to(DEV)), planes_of(w.to(DEV))
+    wf = torch.empty_like(wp)
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), n, k, wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    a = N.WdGemmArgs()
+    s0 = N.WdSrc()
+    s0.hi, s0.lo, s0.ld, s0.c, s0.ntaps = xp[0].data_ptr(), xp[1].data_ptr(), k, k, 1
+    a.src[0] = s0
+    a.nsrc, a.npass = 1, 3
+    a.w_hi, a.w_lo, a.w_layout = wf[0].data_ptr(), wf[1].data_ptr(), 3
+    a.m, a.n, a.ktot, a.hw_out = m, n, k, 1
+    bd, rd, gd, btd = bias.to(DEV), res.to(DEV), gam.to(DEV), bet.to(DEV)
+    a.bias = bd.data_ptr()
+    if resid:
+        a.resid, a.resid_ld = rd.data_ptr(), n
+    out = torch.full((m, n), float("nan"), device=DEV)
+    opl = torch.zeros(2, m, n, dtype=torch.bfloat16, device=DEV)
+    a.out_f32, a.out_ld = out.data_ptr(), n
+    a.out_hi, a.out_lo, a.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), n
+    a.ln_gamma, a.ln_beta, a.ln_eps = gd.data_ptr(), btd.data_ptr(), 1e-5
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm + LayerNorm")
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 2e-5
+    assert max_rel(unplanes(opl).cpu(), refn) < 5e-5
+    a.w_layout = 0
+    a.w_hi, a.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
+    assert lib.wd_gemm(C.byref(a), _st()) != 0  # the LDS-staged tiles (128 x 160) do not hold whole rows
+
+
 @pytest.mark.parametrize("m,inner,npass,planes", [(64, 1280, 3, True), (200, 1280, 3, False), (4096, 1280, 3, True), (130, 256, 1, True)])
 def test_fused_geglu_feed_forward(m, inner, npass, planes):
     """wd_ff_fused: x + GEGLU(LN(x) W1^T + b1) W2^T + b2 (unet.py:122-149, 343-344) in one launch - hidden activations never

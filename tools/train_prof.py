@@ -1,4 +1,6 @@
-"""A few TrainStep iterations at the headline shape (for rocprofv3 --kernel-trace --stats)."""
+"""TrainStep iterations at the headline shape (for rocprofv3 --kernel-trace --stats).  STEPS (default 25): the one-time work of
+the first step - plan building, ~700 buffer fills, weight uploads - is in the trace as well; divide the per-step kernels by STEPS
+and read FillFunctor / copyBuffer as set-up, not as per-step cost."""
 import copy
 import os
 import sys
@@ -13,7 +15,7 @@ from worddiffusion_amd.synthetic import synthetic_inputs  # noqa: E402
 from worddiffusion_amd.training import TrainStep  # noqa: E402
 
 B = int(os.environ.get("B", "64"))
-steps = int(os.environ.get("STEPS", "5"))
+steps = int(os.environ.get("STEPS", "25"))
 dev = "cuda:0"
 model, args = bench.build_model(dev, os.environ.get("PREC", "bf16x3"), "base")
 model.train()

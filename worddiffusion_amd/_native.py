@@ -41,7 +41,7 @@ class WdGemmArgs(C.Structure):
                 ("tickets", _vp), ("ntickets", C.c_int32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_eps", C.c_float),
                 ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32), ("a32", _vp), ("a32_ld", C.c_int32), ("a32_part", _vp),
                 ("a32_nchunk", C.c_int32), ("a32_pcpg", C.c_int32), ("a32_cpg", C.c_int32), ("a32_gamma", _vp), ("a32_beta", _vp),
-                ("a32_eps", C.c_float), ("a32_silu", C.c_int32)]
+                ("a32_eps", C.c_float), ("a32_silu", C.c_int32), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", C.c_float)]
 
 
 class WdFfArgs(C.Structure):

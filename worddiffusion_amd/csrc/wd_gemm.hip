@@ -2217,7 +2217,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.w_layout == 3) {
         // fragment-major weights (wd_gemm_pack_w): the 64 x 320 weights-to-registers kernel only
         if (a.n % 160 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160) || a.ktot % 64) return WD_EINVAL;
-        if (a.tile == 0) a.tile = a.a32 ? 64320 : 128160;
+        if (a.tile == 0) a.tile = (a.a32 || a.ln_gamma) ? 64320 : 128160;
         if (a.n % (a.tile % 1000)) return WD_EINVAL;
     }
     if (a.stat_part) {
@@ -2231,6 +2231,15 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (a.tile == 0) a.tile = bm * 1000 + bn;  // keep 128-row panels (no 64x64 fallback)
     }
     if (a.ksplit > 1 && (!a.ws || a.act == WD_ACT_GEGLU || a.w_layout == 1)) return WD_EINVAL;
+    if (a.ln_gamma) {
+        // row LayerNorm of the result: the tile must hold whole rows and the epilogue must run in the GEMM launch itself
+        if (a.w_layout != 3 || (a.tile && a.tile != 64320) || a.n != 320 || a.ksplit > 1 || !a.ln_beta || !a.out_hi || (a.out_pl_ld & 3) ||
+            ((reinterpret_cast<uintptr_t>(a.ln_gamma) | reinterpret_cast<uintptr_t>(a.ln_beta)) & 15) ||
+            ((reinterpret_cast<uintptr_t>(a.out_hi) | reinterpret_cast<uintptr_t>(a.out_lo)) & 7) || a.act == WD_ACT_GEGLU)
+            return WD_EINVAL;
+        a.tile = 64320;
+        a.ksplit = 1;
+    }
     if (a.gn_gamma) {
         // GroupNorm of the result in the combine launch (wd_reduce_gn_tile): whole (sample, group) blocks per 64 x 40 tile
         if (!a.gn_beta || !a.stat_part || !a.out_hi || !a.ws || a.hw_out != 64 || a.m % 64 || a.n % 160 || a.gn_cpg <= 0 ||

@@ -52,9 +52,9 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
             if (a.rowvec) v += a.rowvec[(long)(m / a.hw_out) * a.rowvec_ld + no];
             if (a.resid) v += a.resid[(a.resid_rows ? (long)a.resid_rows[m] : (long)m) * a.resid_ld + no];
             if (a.act == WD_ACT_SILU) v = wd_silu(v);
-            if (stats) ep[row * LDE + c] = v;
+            if (stats || a.ln_gamma) ep[row * LDE + c] = v;
             if (a.out_f32) a.out_f32[(long)m * a.out_ld + no] = v;
-            if (a.out_hi) {
+            if (a.out_hi && !a.ln_gamma) {
                 uint32_t hb, lb;
                 wd_split1(v, hb, lb);
                 a.out_hi[(long)m * a.out_pl_ld + no] = (wd_bf16)hb;
@@ -131,9 +131,12 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
                     ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
                     ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
                 }
+                if (a.ln_gamma) {  // the row LayerNorm below reads the finished values back from the image
+                    if constexpr (!WS) *reinterpret_cast<float4*>(ep + row * LDE + c) = v;
+                }
                 if (no + 3 < nout) {
                     if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (long)m * a.out_ld + no) = v;
-                    if (a.out_hi) {
+                    if (a.out_hi && !a.ln_gamma) {
                         uint2 hh, ll;
                         wd_split4(v, hh, ll);
                         *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + no) = hh;
@@ -163,6 +166,52 @@ __device__ __forceinline__ void wd_epilogue_from_image(const wd_gemm_args& a, fl
                     *reinterpret_cast<float4*>(o) = cur ? make_float4(ssum.x, ssq.x, ssum.y, ssq.y) : make_float4(0, 0, 0, 0);
                     *reinterpret_cast<float4*>(o + 4) = cur ? make_float4(ssum.z, ssq.z, ssum.w, ssq.w) : make_float4(0, 0, 0, 0);
                 }
+            }
+        }
+    }
+    if (a.ln_gamma) {
+        // ---- LayerNorm of every finished row -> the operand planes of the next GEMM (nn.LayerNorm of the transformer block that
+        // consumes this tensor, unetPhosc.py:241-246): the tile holds whole rows (BN == n, the host checked), one wave per row,
+        // two-pass statistics in registers as wd_layernorm does.  Saves the wd_layernorm launch and its pass over the tensor.
+        __syncthreads();
+        constexpr int NW = NT / 64;
+        const int lane = tid & 63, wv = tid >> 6;
+        const bool has0 = lane * 4 < BN, has1 = (64 + lane) * 4 < BN;
+        // (a lane's columns are the same for every row: the affine vectors are loaded once, not once per row)
+        float4 gq[2], bq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            gq[h] = bq[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h ? has1 : has0) {
+                gq[h] = *reinterpret_cast<const float4*>(a.ln_gamma + (h * 64 + lane) * 4);
+                bq[h] = *reinterpret_cast<const float4*>(a.ln_beta + (h * 64 + lane) * 4);
+            }
+        }
+        for (int row = wv; row < BM; row += NW) {
+            const int m = m0 + row;
+            if (m >= a.m) break;
+            const float* rp = ep + row * LDE;
+            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+            if (has0) x0 = *reinterpret_cast<const float4*>(rp + lane * 4);
+            if (has1) x1 = *reinterpret_cast<const float4*>(rp + (64 + lane) * 4);
+            const float mean = wd_wave_sum((x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w)) * (1.0f / BN);
+            float d = 0.f;
+            if (has0) d += (x0.x - mean) * (x0.x - mean) + (x0.y - mean) * (x0.y - mean) + (x0.z - mean) * (x0.z - mean) + (x0.w - mean) * (x0.w - mean);
+            if (has1) d += (x1.x - mean) * (x1.x - mean) + (x1.y - mean) * (x1.y - mean) + (x1.z - mean) * (x1.z - mean) + (x1.w - mean) * (x1.w - mean);
+            const float rstd = rsqrtf(wd_wave_sum(d) * (1.0f / BN) + a.ln_eps);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!(h ? has1 : has0)) continue;
+                const int c = (h * 64 + lane) * 4;
+                const float4 x = h ? x1 : x0;
+                const float4 g = gq[h], b = bq[h];
+                float4 y;
+                y.x = (x.x - mean) * rstd * g.x + b.x; y.y = (x.y - mean) * rstd * g.y + b.y;
+                y.z = (x.z - mean) * rstd * g.z + b.z; y.w = (x.w - mean) * rstd * g.w + b.w;
+                uint2 hh, ll;
+                wd_split4(y, hh, ll);
+                *reinterpret_cast<uint2*>(a.out_hi + (long)m * a.out_pl_ld + c) = hh;
+                if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + (long)m * a.out_pl_ld + c) = ll;
             }
         }
     }

@@ -308,6 +308,7 @@ class UNetEngine:
         self.fuse_proj = os.environ.get("WDIFF_FUSE_PROJ", "1") != "0"   # ... and proj_out + residual in the same launch
         # GroupNorm (+ SiLU) of a convolution's input applied while the weights-to-registers kernel stages its rows (no wd_gn_apply
         # launch, no operand planes of the normalised map)
+        self.fuse_ln = os.environ.get("WDIFF_FUSE_LN", "1") != "0"  # LayerNorm of a 320-column GEMM result in its own epilogue
         self.fuse_gn_in = int(os.environ.get("WDIFF_FUSE_GN_IN", "1"))  # 0 off, 1 the 1x1 consumers, 2 the 3x3 consumers too
         self.use_slab = os.environ.get("WDIFF_SLAB", "0") != "0"
         self.fuse_stats = os.environ.get("WDIFF_FUSE_STATS", "1") != "0"
@@ -556,7 +557,7 @@ class UNetEngine:
 
     def _gemm(self, ops, what, srcs, wname, m, hw_out, bias=None, rowvec=None, rowvec_ld=0, resid=None,
               resid_ld=0, resid_rows=None, act=N.ACT_NONE, out_f32=None, out_ld=0, out_pl=None, n=None, tile=0,
-              w_row_off=0, want_stats=False, a32=None):
+              w_row_off=0, want_stats=False, a32=None, ln=None):
         """a32 = (Act, norm name, eps, silu): src[0] is that fp32 map, normalised while it is staged (wd_gemm_args.a32*)."""
         a = N.WdGemmArgs()
         for i, s in enumerate(srcs):
@@ -620,6 +621,9 @@ class UNetEngine:
         if out_pl is not None:
             a.out_hi, a.out_lo, a.out_pl_ld = out_pl[0].data_ptr(), out_pl[1].data_ptr(), out_pl.shape[2]
         a.tile = tile
+        if ln is not None:  # out_pl receives LayerNorm(result) * gamma + beta (name of the norm's packed vectors)
+            assert wdirect and nrows == 320 and out_pl is not None, what
+            a.ln_gamma, a.ln_beta, a.ln_eps = self._w[ln + ".g"].data_ptr(), self._w[ln + ".b"].data_ptr(), 1e-5
         stats = None
         if want_stats and self.fuse_stats and nrows % 32 == 0 and (hw_out % 128 == 0 or hw_out == 64):
             cpg = nrows // 32
@@ -745,6 +749,12 @@ class UNetEngine:
             s.stats = (part, nchunk, pc)
         return (s.c // 32) % s.stats[2] == 0
 
+    def _ln_in_producer(self, M, ncols) -> bool:
+        """Does a 1x1 / linear GEMM with these output dimensions run as 64 x 320 weights-to-registers tiles holding whole rows
+        (so that its epilogue can emit the next LayerNorm, wd_gemm_args.ln_*)?"""
+        return (self.fuse_ln and self.use_wdirect and not self.use_slab and not self.use_conv3 and ncols == 320 and
+                (M + 63) // 64 >= 256)
+
     def _src32(self, x: Act, ntaps=1, gather=None, hw_src=0) -> N.WdSrc:
         """src[0] of a GEMM that reads the fp32 map itself (a32): channel count, taps and gather table only."""
         s = N.WdSrc()
@@ -852,13 +862,18 @@ class UNetEngine:
         inner = heads * d
         L = self._ctx_len
         tok = self._f32(P, M, inner)
+        # (PHOSC variant: the first block's norm1 planes come out of proj_in's epilogue where its tiles hold whole rows)
+        n1_pre = None
+        ln1 = None
+        if self.variant == "phosc" and self._ln_in_producer(M, inner):
+            n1_pre, ln1 = self._planes(P, M, inner), f"{name}.tb0.norm1"
         if self._gn_in_consumer(P, ops, name + ".gn", [x], False, M, hw, inner):
             self._gemm(ops, name + ".proj_in", [self._src32(x, hw_src=hw)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
-                       out_f32=tok, out_ld=inner, a32=(x, name + ".gn", 1e-6, False))
+                       out_f32=tok, out_ld=inner, a32=(x, name + ".gn", 1e-6, False), out_pl=n1_pre, ln=ln1)
         else:
             g, _ = self._gn(P, ops, name + ".gn", [x], name + ".gn", 1e-6, False)
             self._gemm(ops, name + ".proj_in", [self._src(g, c)], name + ".pi.w", M, hw, bias=self._w[name + ".pi.b"],
-                       out_f32=tok, out_ld=inner)
+                       out_f32=tok, out_ld=inner, out_pl=n1_pre, ln=ln1)
         xpl = None
         fuse = self.fuse_xattn and bool(self.lib.wd_xattn_supported(inner, heads, L))
 
@@ -919,15 +934,17 @@ class UNetEngine:
             if n3 is not None:
                 pass
             elif self.variant == "phosc":
-                n1 = self._ln(P, ops, p + ".norm1", tok, M, inner, p + ".norm1")
+                n1 = n1_pre if (di == 0 and n1_pre is not None) else self._ln(P, ops, p + ".norm1", tok, M, inner, p + ".norm1")
                 qkv = self._f32(P, M, 3 * inner)
                 self._gemm(ops, p + ".a1.qkv", [self._src(n1, inner)], p + ".a1.qkv.w", M, hw, out_f32=qkv,
                            out_ld=3 * inner)
                 o1 = self._planes(P, M, inner)
                 self._attention(ops, p + ".a1", qkv.data_ptr(), 3 * inner, qkv.data_ptr() + 4 * inner, 3 * inner,
                                 qkv.data_ptr() + 8 * inner, 3 * inner, heads, hw, hw, d, scale, o1)
+                n2_pre = self._planes(P, M, inner) if (not fuse and self._ln_in_producer(M, inner)) else None
                 self._gemm(ops, p + ".a1.out", [self._src(o1, inner)], p + ".a1.o.w", M, hw, bias=self._w[p + ".a1.o.b"],
-                           resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner)
+                           resid=tok.data_ptr(), resid_ld=inner, out_f32=tok1, out_ld=inner, out_pl=n2_pre,
+                           ln=(p + ".norm2") if n2_pre is not None else None)
             elif fuse:
                 folded("a1", p, tok, tok1, "norm2")  # the base model reads norm2 for both attentions (unet.py:337-345)
             else:
@@ -948,7 +965,8 @@ class UNetEngine:
                 n3 = folded("a2", p, tok1, tok2, "norm2", next_ln="norm3")
             else:
                 tok2 = self._f32(P, M, inner)
-                n2 = self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
+                n2 = n2_pre if (self.variant == "phosc" and n2_pre is not None) else \
+                    self._ln(P, ops, p + ".norm2", tok1, M, inner, p + ".norm2")
                 q2 = self._f32(P, M, inner)
                 self._gemm(ops, p + ".a2.q", [self._src(n2, inner)], p + ".a2.q.w", M, hw, out_f32=q2, out_ld=inner)
                 ko = self.kv_off[p + ".a2"]
@@ -968,8 +986,11 @@ class UNetEngine:
                 else:
                     self._attention(ops, p + ".a2", q2.data_ptr(), inner, kp, self.kv_total, vp, self.kv_total, heads, hw, L, d,
                                     scale, o2)
+                if self._ln_in_producer(M, inner):
+                    n3 = self._planes(P, M, inner)
                 self._gemm(ops, p + ".a2.out", [self._src(o2, inner)], p + ".a2.o.w", M, hw, bias=self._w[p + ".a2.o.b"],
-                           resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner)
+                           resid=tok1.data_ptr(), resid_ld=inner, out_f32=tok2, out_ld=inner, out_pl=n3,
+                           ln=(p + ".norm3") if n3 is not None else None)
             # ---- GEGLU feed-forward
             if n3 is None:
                 n3 = self._ln(P, ops, p + ".norm3", tok2, M, inner, p + ".norm3")
