@@ -684,7 +684,18 @@ def main():
             phosc_extra = dict(workload="configs[4] on one GPU: UNetModelPhosc (args.phosc = 1), batch %d, 10 text + 769 PHOSC tokens, "
                                         "200 graph-replayed steps" % B, ms_per_step=pms,
                                images_per_sec=B * 1e3 / (pms * (T - 1)), per_call_setup_ms=pr.setup_ms,
-                               output_finite=bool(torch.isfinite(pr.P.x_in).all().item()))
+                               output_finite=bool(torch.isfinite(pr.P.x_in).all().item()), launches_per_step=len(pr.P.step) + 2)
+            if not a.no_roofline:
+                proof, pclasses = roofline_leg(pr, a.precision)
+                # the attention class of this variant is MFMA work: 2 * 2 * B * heads * nq * nk * d per attention (QK^T and PV),
+                # self-attention over the map's own positions + cross-attention over the 779-token context, per block
+                att_fl = sum(4.0 * B * 4 * hw * (hw + 779) * 80 for hw in (256, 64, 256, 256))
+                ac = pclasses.get("attention", {})
+                if ac.get("ms_per_step"):
+                    tf = att_fl / (ac["ms_per_step"] * 1e-3) / 1e12
+                    ac.update(gflop_per_step=att_fl / 1e9, tflops=tf, mfma_frac=tf / PEAK_BF16_TFLOPS)
+                phosc_extra["roofline"] = proof
+                phosc_extra["kernel_classes"] = pclasses
             del pr, pm
             torch.cuda.empty_cache()
         except Exception as e:  # an extra: never costs the headline line

@@ -199,6 +199,10 @@ int wd_ff_args_bytes(void);
 int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats);
 /* sizeof(wd_gemm_args) as this library was built: a binding that mirrors the struct (ctypes, cgo, ...) compares its own. */
 int wd_gemm_args_bytes(void);
+/* 1 when the library was built with -DWDIFF_EXPERIMENTAL: the opt-in GEMM variants that measured slower than the defaults (slab
+ * order w_layout 1, the row-shared-taps convolution WDIFF_CONV3, the loader-wave ring WDIFF_GEMM_V8, the ping-pong K-half
+ * WDIFF_GEMM_PP) are then compiled in; otherwise w_layout 1 is an error and the other switches are ignored. */
+int wd_gemm_experimental(void);
 
 /* GroupNorm statistics, unet.py:427-431 (eps 1e-5) and :161-162 (eps 1e-6).  x: [B*hw][ld] fp32 with c channels in
  * groups of cpg.  Writes per (sample, chunk, group) partial (sum, sumsq) in double: part[((b*nchunk + j)*(c/cpg) + g)*2],

@@ -54,6 +54,8 @@ def run_gemm(a_list, w, m, hw_out, npass=3, bias=None, rowvec=None, resid=None, 
     args.nsrc, args.npass = len(a_list), npass
     wp = planes_of(w)
     if slab:
+        if not lib.wd_gemm_experimental():
+            pytest.skip("slab kernel: library built without WDIFF_EXPERIMENTAL")
         g0 = a_list[0][3]
         span = slab_span(g0.cpu().numpy() if g0 is not None else None, hw_out, a_list[0][4], m)
         if span > 192 or tile == 64064:
@@ -530,6 +532,8 @@ def test_gemm_deep_pipeline_kernel(B, hh, ww, c1, c2, n, ksplit, npass, sel):
     3x3 gather source + optional identity skip source, FiLM row vector, residual, planes out, ragged M / N, split-K, short K loops
     (1 .. 3 stages: the prologue / drain paths), single-pass bf16 - vs fp64 and vs the v2 kernel; repeated launches give the same bits
     (a race between the LDS-DMA ring and the fragment reads would not)."""
+    if not N.lib().wd_gemm_experimental():
+        pytest.skip("library built without WDIFF_EXPERIMENTAL")
     g = torch.Generator().manual_seed(B + hh + ww + c1 + n)
     hw, m = hh * ww, B * hh * ww
     a1 = torch.randn(m, c1, generator=g)
@@ -559,6 +563,8 @@ def test_gemm_deep_pipeline_kernel(B, hh, ww, c1, c2, n, ksplit, npass, sel):
 @pytest.mark.parametrize("k,sel", [(32, 0x80000), (64, 0x80000), (96, 0x80000), (128, 0x80000), (160, 0x80000), (320, 0x80000)])
 def test_gemm_deep_pipeline_kernel_short_loops(k, sel):
     """1 .. 10 stages of a plain linear through wd_gemm8_kernel: every length of the prologue / steady state / drain."""
+    if not N.lib().wd_gemm_experimental():
+        pytest.skip("library built without WDIFF_EXPERIMENTAL")
     g = torch.Generator().manual_seed(k)
     m, n = 300, 320
     a, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
@@ -956,6 +962,8 @@ def test_conv3x3_row_shared_taps_kernel(B, h, w, cin, cout, skip, ksplit, form):
     """wd_gemm with w_layout 2 (wd_conv3_kernel, forced by dbg 0x1000: the three taps of a kernel row share one A tile, 16x16x32 MFMA,
     stagger) vs F.conv2d (+ 1x1 skip over a second source), incl. panels that straddle samples, narrow / wide images, split-K, and
     the headline shape."""
+    if not N.lib().wd_gemm_experimental():
+        pytest.skip("library built without WDIFF_EXPERIMENTAL")
     g = torch.Generator().manual_seed(B * 100 + h * 10 + w + cin)
     x = torch.randn(B, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5

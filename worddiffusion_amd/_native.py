@@ -60,6 +60,7 @@ _SIGS = {
     "wd_ff_supported": (_i, [_i, _i]),
     "wd_ff_args_bytes": (_i, []),
     "wd_gemm_args_bytes": (_i, []),
+    "wd_gemm_experimental": (_i, []),
     "wd_gn_nchunk": (_i, [_i]),
     "wd_gn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "wd_gn_fold_chunks": (_i, [_vp, _i, _i, _i, _vp, _vp]),

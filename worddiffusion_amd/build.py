@@ -17,6 +17,8 @@ LIB = os.path.join(HERE, "libwdiff_hip.so")
 SOURCES = ["wd_gemm.hip", "wd_gemmw.hip", "wd_ff.hip", "wd_norm.hip", "wd_attn.hip", "wd_xattn.hip", "wd_misc.hip", "wd_train.hip", "wd_bwd.hip", "wd_pack.hip", "wd_runtime.hip"]
 HEADERS = [os.path.join(CSRC, "wd_common.h"), os.path.join(CSRC, "wd_gemm_epi.h"), os.path.join(CSRC, "wd_gemm_priv.h"), os.path.join(os.path.dirname(HERE), "include", "wdiff_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+if os.environ.get("WDIFF_EXPERIMENTAL", "0") != "0":  # the opt-in GEMM variants that lost their A/B (csrc/wd_gemm.hip)
+    FLAGS.append("-DWDIFF_EXPERIMENTAL")
 
 
 def _hipcc() -> str:

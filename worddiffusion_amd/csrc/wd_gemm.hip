@@ -980,6 +980,8 @@ __global__ void __launch_bounds__(256, 2) wd_gemm4_kernel(const wd_gemm_args a, 
 #endif
 }
 
+// ---- opt-in kernels that lost their A/B against the defaults: compiled with -DWDIFF_EXPERIMENTAL only
+#ifdef WDIFF_EXPERIMENTAL
 // ======================================================================================================
 // v3 "slab" kernel: the A operand of a 3x3 convolution is NOT re-fetched per tap.  For a panel of BM output rows
 // the union of source rows over all taps is a short contiguous range (a few image rows + halo): that slab is
@@ -1280,6 +1282,8 @@ int launch3(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
+#endif  // WDIFF_EXPERIMENTAL
+
 template <int BM, int BN, int NPASS>
 int launch(const wd_gemm_args& a, hipStream_t st) {
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
@@ -1501,6 +1505,7 @@ int launch2(const wd_gemm_args& a, hipStream_t st) {
 }
 
 
+#ifdef WDIFF_EXPERIMENTAL
 // ======================================================================================================
 // Row-shared-taps kernel for the 3x3 / pad 1 / stride 1 convolutions (w_layout == 2; slab_rows = image width W).
 // The per-stage cycle stamps of the kernel above show that a global_load_lds piece costs its wave 100-185 issue cycles while
@@ -2167,6 +2172,8 @@ int launch8(const wd_gemm_args& a, hipStream_t st) {
     return wd_check_launch();
 }
 
+#endif  // WDIFF_EXPERIMENTAL
+
 }  // namespace
 
 int wd_gemm_launch_reduce(const wd_gemm_args& a, hipStream_t st, int bm) {
@@ -2200,6 +2207,14 @@ static int wd_auto_tile(const int m, const int n, const int nk64, const bool can
     const bool can_split = can_split_base && nk64 >= 8 && (long)2 * m * n <= ws_floats;
     if (tiles < 128 && !can_split && m > 64) tile = 64064;
     return tile;
+}
+
+extern "C" int wd_gemm_experimental(void) {  // 1: built with -DWDIFF_EXPERIMENTAL (slab / row-shared-taps / ring kernels present)
+#ifdef WDIFF_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int wd_gemm_args_bytes(void) { return (int)sizeof(wd_gemm_args); }  // (callers that mirror the struct check their layout)
@@ -2304,6 +2319,9 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         a.tickets = nullptr;
         return wd_gemmw_launch(a, st);
     }
+#ifndef WDIFF_EXPERIMENTAL
+    if (a.w_layout == 1) return WD_EINVAL;  // (the slab kernel is an experimental build option)
+#else
     if (a.w_layout == 1) {
         // slab-order weights: v3 kernel only.  Contract: c % 32 == 0 (checked above), src[1] identity, slab_rows set.
         if (a.src[0].ntaps > 9 || a.slab_rows <= 0) return WD_EINVAL;
@@ -2324,13 +2342,19 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         }
 #undef WD_DISPATCH3
     }
+#endif
     bool conv3 = false;
     if (a.w_layout == 2) {
         // row-shared taps (wd_conv3_kernel): 3x3 / pad 1 / stride 1 over images of width slab_rows, optional identity source.
         // The operand layout is the ordinary one, so this is a hint: shapes the kernel does not cover take the generic path.
         const wd_src& q0 = a.src[0];
         static const int conv3_mode = getenv("WDIFF_CONV3") ? atoi(getenv("WDIFF_CONV3")) : 0;
+#ifdef WDIFF_EXPERIMENTAL
         const bool conv3_env = conv3_mode != 0 || (a.dbg & 0x1000);  // (dbg 0x1000: the parity tests pick the kernel)
+#else
+        const bool conv3_env = false;
+        (void)conv3_mode;
+#endif
         const bool same3 = q0.ntaps == 9 && q0.gather && a.slab_rows > 0 && q0.hw_src == a.hw_out && a.hw_out % a.slab_rows == 0;
         conv3 = conv3_env && same3 && q0.c % 64 == 0 && a.act != WD_ACT_GEGLU && (a.tile == 0 || a.tile == 128160) &&
                 (a.nsrc == 1 || (!a.src[1].gather && a.src[1].ntaps == 1 && a.src[1].c % 64 == 0));
@@ -2391,19 +2415,28 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     static const bool stagger = getenv("WDIFF_GEMM_STAGGER") ? atoi(getenv("WDIFF_GEMM_STAGGER")) != 0 : true;
     static const bool m16 = getenv("WDIFF_GEMM_M16") ? atoi(getenv("WDIFF_GEMM_M16")) != 0 : true;
     static const bool pp = getenv("WDIFF_GEMM_PP") ? atoi(getenv("WDIFF_GEMM_PP")) != 0 : false;  // measured: no gain
+#ifdef WDIFF_EXPERIMENTAL
+#define WD_DISPATCH_PP(BM_, BN_) \
+    if (v2ok && ks == 2 && pp) return a.npass == 3 ? launch2<BM_, BN_, 3, 2, true>(a, st) : launch2<BM_, BN_, 1, 2, true>(a, st);
+#else
+#define WD_DISPATCH_PP(BM_, BN_) (void)pp;
+#endif
 #define WD_DISPATCH(BM_, BN_)                                                                      \
-    if (v2ok && ks == 2 && pp) return a.npass == 3 ? launch2<BM_, BN_, 3, 2, true>(a, st) : launch2<BM_, BN_, 1, 2, true>(a, st); \
+    WD_DISPATCH_PP(BM_, BN_)                                                                       \
     if (v2ok && ks == 2) return a.npass == 3 ? launch2<BM_, BN_, 3, 2>(a, st) : launch2<BM_, BN_, 1, 2>(a, st); \
     if (v2ok) return a.npass == 3 ? launch2<BM_, BN_, 3, 1>(a, st) : launch2<BM_, BN_, 1, 1>(a, st); \
     a.ksplit = 1;                                                                                   \
     a.tickets = nullptr;                                                                            \
     return a.npass == 3 ? launch<BM_, BN_, 3>(a, st) : launch<BM_, BN_, 1>(a, st)
+#ifdef WDIFF_EXPERIMENTAL
     if (conv3 && v2ok) return a.npass == 3 ? launch_conv3<3>(a, st) : launch_conv3<1>(a, st);
+#endif
     switch (tile) {
         case 128064: WD_DISPATCH(128, 64);
         case 128160:
             // second K-half group runs one stage late (see the kernel); the extra drain phase only pays on long K loops
             if (use_v4) return a.npass == 3 ? launch4<3>(a, st) : launch4<1>(a, st);
+#ifdef WDIFF_EXPERIMENTAL
             {
                 // ring kernel with dedicated loader waves (wd_gemm8_kernel): within +-5 % of the default kernel on every shape; no
                 // fused GroupNorm statistics (its 768-thread epilogue would need a larger statistics scratch).  WDIFF_GEMM_V8=1 takes it wherever legal, dbg 0x80000 forces it (parity tests).
@@ -2417,6 +2450,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
                     return a.npass == 3 ? launch8<3>(a, st) : launch8<1>(a, st);
                 }
             }
+#endif
             if (v2ok && ks == 2 && m16 && stagger && nk64 / a.ksplit >= stagger_min) a.dbg |= 0x200;
             if (v2ok && ks == 2 && m16)
                 return a.npass == 3 ? launch2<128, 160, 3, 2, false, true>(a, st) : launch2<128, 160, 1, 2, false, true>(a, st);

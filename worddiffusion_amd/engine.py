@@ -315,6 +315,9 @@ class UNetEngine:
         self.fuse_xattn = os.environ.get("WDIFF_FUSE_XATTN", "1") != "0"
         # row-shared-taps convolution kernel (29 % fewer DMA pieces, but measured 15 % slower than the generic kernel so far)
         self.use_conv3 = os.environ.get("WDIFF_CONV3", "0") != "0"
+        if (self.use_slab or self.use_conv3) and not self.lib.wd_gemm_experimental():
+            raise N.NativeError("WDIFF_SLAB / WDIFF_CONV3 need a library built with WDIFF_EXPERIMENTAL=1 "
+                                "(python -m worddiffusion_amd.build --force)")
         self.fuse_xattn_pair = os.environ.get("WDIFF_FUSE_XATTN_PAIR", "1") != "0"
         self.fuse_out = os.environ.get("WDIFF_FUSE_OUT", "1") != "0"
         self.pack_kv = os.environ.get("WDIFF_PACK_KV", "1") != "0"         # long-context cross-attention: K/V images built once per call
