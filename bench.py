@@ -515,6 +515,13 @@ def roofline_leg(runner, precision):
                         % (PMC_KEYS[dom], k["fetch_mb_corrected"], k["write_mb"], name))
     except (OSError, KeyError, ValueError, IndexError):
         pass
+    mfma_util = None
+    try:  # MFMA-pipe busy fraction of that kernel from its own PMC pass (tools/pmc_mfma.py)
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        name = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_mfma_util.json"))[-1]
+        mfma_util = json.load(open(os.path.join(pdir, name)))[PMC_KEYS[dom]]["mfma_util_percent"] / 100.0
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
     total_fl = sum(fl[i] for i in CONTRACTION_CLASSES)
     total_ms = sum(ms[i] for i in range(N.NCLASS))
     roof = dict(bound="mfma", kernel=CONTRACTION_CLASSES[dom] + "; hipEvent pair around every launch", achieved=ach,
@@ -523,8 +530,10 @@ def roofline_leg(runner, precision):
                 algorithmic_gflop_per_step=fl[dom] / nprof / 1e9, share_of_step_kernel_time=ms[dom] / total_ms if total_ms else None,
                 all_contractions=dict(gflop_per_step=total_fl / nprof / 1e9,
                                       tflops=total_fl / (sum(ms[i] for i in CONTRACTION_CLASSES) * 1e-3) / 1e12),
-                mfma_issue_factor=3 if precision == "bf16x3" else 1,
-                note="achieved counts each multiply-add once; the split-bf16 path issues 3 MFMAs per product")
+                mfma_issue_factor=3 if precision == "bf16x3" else 1, mfma_pipe_busy_pmc=mfma_util,
+                note="achieved counts each multiply-add once; the split-bf16 path issues 3 MFMAs per product; mfma_pipe_busy_pmc = "
+                     "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) of that kernel from a separate rocprofv3 --pmc pass "
+                     "(profiles/rNN_pmc_mfma_util.json)")
     return roof, classes
 
 

@@ -18,12 +18,22 @@ echo "[collect] train kernel stats done"
 P="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call --no-phosc"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $P > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 4
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 $P > $OUT/${TAG}_pmc_write.log 2>&1 || exit 5
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -o m -- python3 $P > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 7
+M=$(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1)
+python3 $ROOT/tools/pmc_mfma.py "$M" > $OUT/${TAG}_pmc_mfma_util.json || exit 8
 F=$(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
 python3 $ROOT/tools/pmc_traffic.py "$F" "$W" > $OUT/${TAG}_pmc_hbm_traffic.json || exit 6
 find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train -name "*kernel_stats.csv" | while read f; do cp "$f" $OUT/${TAG}_$(basename $(dirname $(dirname "$f")) | sed "s/${TAG}_prof_//")_kernel_stats.csv 2>/dev/null; done
 # the raw traces are large: keep the summaries only
 find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete
-find $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*counter_collection.csv" -delete
+find $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" -delete
+find $OUT/${TAG}_pmc_mfma -name "*kernel_trace.csv" -delete
+# the per-launch tables and the in-graph timeline of one step
+python3 $ROOT/tools/step_ops.py > $OUT/${TAG}_step_ops.txt 2>/dev/null
+VARIANT=phosc python3 $ROOT/tools/step_ops.py > $OUT/${TAG}_step_ops_phosc.txt 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl -o t -- python3 $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call --no-phosc > $OUT/${TAG}_tl.log 2>&1
+python3 $ROOT/tools/step_timeline.py $(find $OUT/${TAG}_tl -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline.txt
+rm -rf $OUT/${TAG}_tl
 echo "[collect] done"
 ls $OUT | grep "^${TAG}_"

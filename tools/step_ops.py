@@ -36,6 +36,9 @@ with torch.cuda.stream(run.stream):
         if isinstance(obj, N.WdGemmArgs):
             gf = 2.0 * obj.m * obj.n * obj.ktot * 1e-9
             info = f"m={obj.m:6d} n={obj.n:5d} k={obj.ktot:5d} {gf:7.2f} GF {gf / us * 1e3:6.1f} TF/s"
+        if isinstance(obj, N.WdFfArgs):
+            gf = 2.0 * obj.m * (3.0 * obj.inner * obj.c + (obj.c * obj.c if obj.w3_hi else 0)) * 1e-9
+            info = f"m={obj.m:6d} c={obj.c:5d} h={obj.inner:5d} {gf:7.2f} GF {gf / us * 1e3:6.1f} TF/s"
         rows.append((what, getattr(fn, "__name__", str(fn)), us, info))
 tot = sum(r[2] for r in rows)
 for what, name, us, info in rows:
