@@ -441,7 +441,7 @@ CONTRACTION_CLASSES = {
        "the 3x3 convolutions and 1x1 projections of the 8x32 level)",
     10: "wd_ff_kernel<3> (GEGLU feed-forward + residual per 64-token panel, hidden activations on chip)",
 }
-PMC_KEYS = {0: "wd_gemm2_kernel<128, 160, 3, 2, false, true>", 9: "wd_gemmw_kernel<3, 1>", 10: "wd_ff_kernel<3, false>"}
+PMC_KEYS = {0: "wd_gemm2_kernel<128, 160, 3, 2, false, true>", 9: "wd_gemmw_kernel<3, 1, false>", 10: "wd_ff_kernel<3, true>"}
 
 
 def streaming_bytes_per_step(P, lib, npl):

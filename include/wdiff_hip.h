@@ -38,6 +38,8 @@ extern "C" {
 
 typedef uint16_t wd_bf16;
 
+#define WD_MAX_KSPLIT 64 /* largest wd_gemm_args.ksplit */
+
 /* One A-operand source of the tap-gather GEMM.  K contribution = ntaps * c.
  * Row m of the output (sample b = m / hw_out, position p = m % hw_out) reads, for tap t,
  * source row  b*hw_src + gather[t*hw_out + p]  (all-zero row when that entry is < 0);
@@ -89,8 +91,8 @@ typedef struct wd_gemm_args {
                            * gather table) over images of width slab_rows, src[1] (optional) an identity source: selects the
                            * kernel that loads the A tile of a kernel row once for its three taps when WDIFF_CONV3=1; in every case
                            * it lets the kernel compute the source rows of a panel instead of reading the gather table */
-    int32_t ksplit;       /* 1: off.  >1: the K range is cut into ksplit slices run by separate workgroups (fills the chip
-                           * when m*n is small); partial sums go to ws and are combined in fixed order.  0: automatic
+    int32_t ksplit;       /* 1: off.  >1 (at most WD_MAX_KSPLIT): the K range is cut into ksplit slices run by separate workgroups
+                           * (fills the chip when m*n is small); partial sums go to ws and are combined in fixed order.  0: automatic
                            * (splits only when ws is given and the tile grid would leave most CUs idle) */
     float* ws;            /* split-K workspace (ksplit * m * n floats are used) or NULL */
     int64_t ws_floats;    /* capacity of ws in floats */
@@ -393,6 +395,37 @@ int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int
                         int hw_out, int hw_src, int m, int mpad, int tap_minor, wd_bf16* out_hi, wd_bf16* out_lo,
                         void* stream);
 
+/* Weight gradient straight from the row-major operand planes - no transposed copies (csrc/wd_dw.hip):
+ *   grad[n][ci * ntaps + t] (+)= sum over tokens mm < m of  d[mm][n] * x[src(mm, t)][ci]
+ * (the OIHW gradient of nn.Conv2d / nn.Linear under autograd, same layers as wd_transpose_planes above).  d: split-bf16 planes
+ * of d(output) [m][d_ld] (wd_dout_prep's row-major planes); x: the layer's input planes [.][x_ld], pointers at the first of the
+ * c channels; src = row mm (gather NULL, ntaps 1) or sample * hw_src + gather[t * hw_out + position] (zero row for -1) as in
+ * wd_gemm.  The token range is cut into slices run by separate workgroups; their partial tiles go to ws
+ * ([nslice][n][ntaps][c] floats) and are combined in fixed order.  Shapes: wd_dw_supported(). */
+typedef struct wd_dw_args {
+    const wd_bf16* d_hi;
+    const wd_bf16* d_lo;      /* NULL with npass 1 */
+    const wd_bf16* x_hi;
+    const wd_bf16* x_lo;      /* NULL with npass 1 */
+    const int32_t* gather;    /* [ntaps][hw_out] or NULL */
+    float* grad;              /* [n][grad_ld], grad_ld >= c * ntaps */
+    float* ws;
+    int64_t ws_floats;
+    int32_t d_ld, x_ld, grad_ld;
+    int32_t ntaps, hw_out, hw_src;
+    int32_t m, n, c;
+    int32_t npass;            /* 3: hi.hi + hi.lo + lo.hi, 1: hi.hi */
+    int32_t accumulate;       /* 1: grad += */
+    int32_t nslice;           /* 0: automatic (wd_dw_slices), else <= m / 64 */
+    int32_t dbg;
+    int32_t reserved;
+    void* stamps;             /* NULL (debug builds: 16 u64 of cycle sums, see csrc/wd_dw.hip) */
+} wd_dw_args;
+int wd_dw(const wd_dw_args* a, void* stream);
+int wd_dw_supported(int m, int n, int c, int ntaps, int hw_out); /* m % 64, n % 160, c % 160, hw_out % 64 == 0, hw_out <= 1024 */
+int wd_dw_slices(int m, int n, int c, int ntaps);               /* the automatic nslice */
+int wd_dw_args_bytes(void);
+
 /* (bias gradients of the layers above; gradient of the FiLM vector emb_out[..., None, None], unet.py:660-661)
  * out[s][col] (+)= scale * sum over rows [s*seg, (s+1)*seg) of x[row][col]; fixed summation order.
  * scratch: ceil(rows/seg) * ceil(seg/64) * c floats.  (bias gradients: seg = rows; FiLM gradient: seg = hw.) */
@@ -481,10 +514,11 @@ int wd_graph_destroy(void* graph_exec);
 /* per-kernel-class timing with hipEvents recorded on the launch stream (bench.py roofline leg).
  * classes: 0 gemm (the LDS-staged wd_gemm2_kernel<128,160,...>), 1 gn_stats, 2 gn_apply, 3 layernorm, 4 attention, 5 other,
  * 6 gemm with other tile shapes, 7 split-K combine pass, 8 the two-workgroups-per-CU gemm kernel (wd_gemm4_kernel),
- * 9 the weights-to-registers gemm (wd_gemmw_kernel, 64 x 320 / 128 x 160 tiles), 10 the fused feed-forward (wd_ff_kernel).
+ * 9 the weights-to-registers gemm (wd_gemmw_kernel, 64 x 320 / 128 x 160 tiles), 10 the fused feed-forward (wd_ff_kernel),
+ * 11 the weight-gradient kernel (wd_dw_kernel).
  * wd_prof_collect: gemm_flops = the 2*M*N*K of class 0; wd_prof_collect_flops additionally returns the algorithmic FLOPs
- * (each multiply-add counted once) of every class that declares them (the contraction classes 0, 6, 8, 9, 10). */
-#define WD_NCLASS 11
+ * (each multiply-add counted once) of every class that declares them (the contraction classes 0, 6, 8, 9, 10, 11). */
+#define WD_NCLASS 12
 int wd_prof_enable(int on);
 int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
 int wd_prof_collect_flops(double* ms_per_class, int64_t* launches_per_class, double* flops_per_class); /* syncs */

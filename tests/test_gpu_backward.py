@@ -76,6 +76,89 @@ def test_conv_data_and_weight_gradients_through_wd_gemm(mode, B, Ci, h, w, Co):
     assert torch.equal(acc, 2 * perm)
 
 
+def run_dw(lib, dpl, xpl, n, c, m, gather=None, ntaps=1, hw_out=0, hw_src=0, npass=3, nslice=0, acc=None, x_col=0):
+    """wd_dw over planes dpl [2][m][d_ld], xpl [2][rows][x_ld] (channels x_col .. x_col + c) -> grad [n][c * ntaps]."""
+    grad = torch.full((n, c * ntaps), float("nan"), device=DEV) if acc is None else acc.clone()
+    ws = torch.empty(max(nslice, lib.wd_dw_slices(m, n, c, ntaps), 1) * n * c * ntaps, device=DEV)
+    a = N.WdDwArgs()
+    a.d_hi, a.d_lo = dpl[0].data_ptr(), (dpl[1].data_ptr() if npass == 3 else None)
+    a.x_hi, a.x_lo = xpl[0].data_ptr() + 2 * x_col, (xpl[1].data_ptr() + 2 * x_col if npass == 3 else None)
+    a.gather = gather.data_ptr() if gather is not None else None
+    a.grad, a.grad_ld, a.ws, a.ws_floats = grad.data_ptr(), c * ntaps, ws.data_ptr(), ws.numel()
+    a.d_ld, a.x_ld = dpl.shape[2], xpl.shape[2]
+    a.ntaps, a.hw_out, a.hw_src = ntaps, hw_out, hw_src
+    a.m, a.n, a.c, a.npass, a.accumulate, a.nslice = m, n, c, npass, int(acc is not None), nslice
+    N.check(lib.wd_dw(C.byref(a), _st()), "wd_dw")
+    torch.cuda.synchronize()
+    return grad
+
+
+@pytest.mark.parametrize("mode,B,Ci,h,w,Co,nslice", [("same", 4, 320, 8, 32, 320, 0), ("same", 2, 160, 8, 32, 160, 1),
+                                                      ("same", 3, 320, 4, 16, 160, 3), ("down", 2, 160, 8, 32, 320, 2),
+                                                      ("up", 2, 160, 4, 16, 160, 0), ("same", 16, 640, 8, 32, 320, 0)])
+def test_weight_gradient_from_row_major_planes_conv(mode, B, Ci, h, w, Co, nslice):
+    """wd_dw (transposed LDS reads, no transposed copies) against autograd's conv weight gradient, fp64."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B * 7 + Ci + h)
+    x = torch.randn(B, Ci, h, w, generator=g, dtype=torch.float64)
+    wt = (torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64) / (9 * Ci) ** 0.5).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    y = F.conv2d(xin, wt, None, stride=2 if mode == "down" else 1, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ftab, ho, wo = conv_gather_table(h, w, mode)
+    m = B * ho * wo
+    if not lib.wd_dw_supported(m, Co, Ci, 9, ho * wo):
+        pytest.skip("shape outside wd_dw_supported")
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, Ci).float().contiguous()
+    dtok = dy.permute(0, 2, 3, 1).reshape(m, Co).float().contiguous()
+    xpl, dpl = planes_of(tok.to(DEV)), planes_of(dtok.to(DEV))
+    got = run_dw(lib, dpl, xpl, Co, Ci, m, torch.from_numpy(ftab).to(DEV), 9, ho * wo, h * w, nslice=nslice)
+    # reference on the operands the kernel sees (the bf16x2-rounded values), fp64
+    x2 = unplanes(xpl).double().cpu().reshape(B, h, w, Ci).permute(0, 3, 1, 2)
+    d2 = unplanes(dpl).double().cpu().reshape(B, ho, wo, Co).permute(0, 3, 1, 2)
+    w2 = wt.detach().clone().requires_grad_(True)
+    x2in = F.interpolate(x2, scale_factor=2, mode="nearest") if mode == "up" else x2
+    F.conv2d(x2in, w2, None, stride=2 if mode == "down" else 1, padding=1).backward(d2)
+    assert rel_err(got.cpu().reshape(Co, Ci, 3, 3), w2.grad) < 5e-6
+    assert rel_err(got.cpu().reshape(Co, Ci, 3, 3), wt.grad) < 2e-5
+    # accumulation into a gradient that holds a value; one-pass (bf16) mode
+    base = torch.randn(Co, Ci * 9, generator=g).to(DEV)
+    got2 = run_dw(lib, dpl, xpl, Co, Ci, m, torch.from_numpy(ftab).to(DEV), 9, ho * wo, h * w, nslice=nslice, acc=base)
+    assert rel_err((got2 - base).cpu().reshape(Co, Ci, 3, 3), w2.grad) < 2e-5
+    got1 = run_dw(lib, dpl, xpl, Co, Ci, m, torch.from_numpy(ftab).to(DEV), 9, ho * wo, h * w, nslice=nslice, npass=1)
+    x1 = xpl[0].double().cpu().reshape(B, h, w, Ci).permute(0, 3, 1, 2)
+    d1 = dpl[0].double().cpu().reshape(B, ho, wo, Co).permute(0, 3, 1, 2)
+    w1 = wt.detach().clone().requires_grad_(True)
+    x1in = F.interpolate(x1, scale_factor=2, mode="nearest") if mode == "up" else x1
+    F.conv2d(x1in, w1, None, stride=2 if mode == "down" else 1, padding=1).backward(d1)
+    assert rel_err(got1.cpu().reshape(Co, Ci, 3, 3), w1.grad) < 5e-6
+
+
+@pytest.mark.parametrize("m,n,c,ld_extra,x_col,nslice", [(16384, 320, 320, 0, 0, 0), (4096, 2560, 320, 0, 0, 0), (1024, 320, 1280, 64, 0, 5),
+                                                         (512, 160, 160, 32, 160, 4), (128, 160, 160, 0, 0, 0)])
+def test_weight_gradient_from_row_major_planes_linear(m, n, c, ld_extra, x_col, nslice):
+    lib = N.lib()
+    g = torch.Generator().manual_seed(m + n + c)
+    d = torch.randn(m, n + ld_extra, generator=g)
+    x = torch.randn(m, x_col + c + ld_extra, generator=g)
+    dpl, xpl = planes_of(d.to(DEV)), planes_of(x.to(DEV))
+    got = run_dw(lib, dpl, xpl, n, c, m, hw_out=min(m, 256), hw_src=min(m, 256), nslice=nslice, x_col=x_col)
+    ref = unplanes(dpl).double().cpu()[:, :n].t() @ unplanes(xpl).double().cpu()[:, x_col:x_col + c]
+    assert rel_err(got.cpu(), ref) < 5e-6
+    assert rel_err(got.cpu(), d.double()[:, :n].t() @ x.double()[:, x_col:x_col + c]) < 2e-5
+
+
+def test_weight_gradient_kernel_rejects_bad_arguments():
+    lib = N.lib()
+    assert not lib.wd_dw_supported(100, 320, 320, 9, 50)
+    assert not lib.wd_dw_supported(256, 300, 320, 9, 256)
+    assert not lib.wd_dw_supported(256, 320, 64, 1, 256)
+    assert lib.wd_dw_supported(16384, 320, 640, 9, 256)
+    a = N.WdDwArgs()
+    assert lib.wd_dw(C.byref(a), _st()) == N.WD_EINVAL
+
+
 def test_transpose_planes_and_colsum():
     lib = N.lib()
     g = torch.Generator().manual_seed(1)

@@ -35,6 +35,7 @@ SHAPES = {
 
 
 def main():
+    global B
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="all")
     ap.add_argument("--tile", type=int, default=0)
@@ -51,7 +52,15 @@ def main():
                     "the result is compared with the default kernel's first")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
                     "2: same, then read the weights once (emulates a prefetch) before the launch")
+    ap.add_argument("--mnk", default="", help="m,n,k of a plain product (no taps) instead of --shape, e.g. 320,320,16384: the "
+                    "weight-gradient GEMMs of the training step (reduction over the tokens)")
     a = ap.parse_args()
+    if a.mnk:
+        mm, nn, kk = (int(v) for v in a.mnk.split(","))
+        SHAPES["mnk"] = (1, mm, kk, nn, "lin")
+        a.shape, a.batch = "mnk", 1
+    if a.batch:
+        B = a.batch
     lib = N.lib()
     st = torch.cuda.current_stream().cuda_stream
     names = list(SHAPES) if a.shape == "all" else a.shape.split(",")
@@ -84,7 +93,7 @@ def main():
         g.tile = a.tile if kind != "geglu" or a.tile else 0
         g.dbg = a.dbg
         g.ksplit = a.ksplit
-        ws = torch.empty(8 * m * cout if a.ksplit != 1 and m * cout * 8 < 2 ** 28 else 1, device=DEV)
+        ws = torch.empty(max(8, a.ksplit) * m * cout if a.ksplit != 1 and m * cout * max(8, a.ksplit) < 2 ** 28 else 1, device=DEV)
         if a.ksplit != 1:
             g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
         tk = torch.zeros(8192, dtype=torch.int32, device=DEV)

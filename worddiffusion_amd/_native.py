@@ -15,9 +15,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wdiff_hip.h")
 
 WD_OK, WD_EINVAL, WD_ELAUNCH, WD_ESTATE = 0, -1, -2, -3
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
-NCLASS = 11
+NCLASS = 12
 CLASS_NAMES = ("gemm", "gn_stats", "gn_apply", "layernorm", "attention", "other", "gemm_other_tiles", "gemm_splitk_reduce",
-               "gemm_two_per_cu", "gemm_weights_to_registers", "feed_forward_fused")
+               "gemm_two_per_cu", "gemm_weights_to_registers", "feed_forward_fused", "weight_gradient")
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -52,8 +52,20 @@ class WdFfArgs(C.Structure):
                 ("stat_part", _vp), ("stat_cpg", C.c_int32), ("hw_out", C.c_int32), ("npass", C.c_int32)]
 
 
+class WdDwArgs(C.Structure):
+    _fields_ = [("d_hi", _vp), ("d_lo", _vp), ("x_hi", _vp), ("x_lo", _vp), ("gather", _vp), ("grad", _vp), ("ws", _vp),
+                ("ws_floats", C.c_int64), ("d_ld", C.c_int32), ("x_ld", C.c_int32), ("grad_ld", C.c_int32), ("ntaps", C.c_int32),
+                ("hw_out", C.c_int32), ("hw_src", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("c", C.c_int32),
+                ("npass", C.c_int32), ("accumulate", C.c_int32), ("nslice", C.c_int32), ("dbg", C.c_int32), ("reserved", C.c_int32),
+                ("stamps", _vp)]
+
+
 _SIGS = {
     "wd_gemm": (_i, [C.POINTER(WdGemmArgs), _vp]),
+    "wd_dw": (_i, [C.POINTER(WdDwArgs), _vp]),
+    "wd_dw_supported": (_i, [_i, _i, _i, _i, _i]),
+    "wd_dw_slices": (_i, [_i, _i, _i, _i]),
+    "wd_dw_args_bytes": (_i, []),
     "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
     "wd_gemm_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "wd_ff_fused": (_i, [C.POINTER(WdFfArgs), _vp]),
@@ -170,6 +182,9 @@ def lib() -> C.CDLL:
                           "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     if l.wd_ff_args_bytes() != C.sizeof(WdFfArgs):
         raise NativeError(f"{LIB_PATH}: wd_ff_args is {l.wd_ff_args_bytes()} bytes in the library, {C.sizeof(WdFfArgs)} in "
+                          "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
+    if l.wd_dw_args_bytes() != C.sizeof(WdDwArgs):
+        raise NativeError(f"{LIB_PATH}: wd_dw_args is {l.wd_dw_args_bytes()} bytes in the library, {C.sizeof(WdDwArgs)} in "
                           "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     _lib = l
     return l

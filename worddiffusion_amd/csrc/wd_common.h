@@ -16,6 +16,7 @@
 #define WD_CLS_GEMM_2CU 8     // wd_gemm4_kernel (two workgroups per CU)
 #define WD_CLS_GEMM_WDIRECT 9 // wd_gemmw_kernel (weights straight to registers)
 #define WD_CLS_FF 10          // wd_ff_kernel (fused GEGLU feed-forward)
+#define WD_CLS_DW 11          // wd_dw_kernel (weight gradients from the row-major planes)
 
 // ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
 extern "C" int wd_prof_is_on();

@@ -2194,7 +2194,11 @@ static int wd_auto_ksplit(const int tile, const int m, const int n, const int nk
     if (!((tiles < 128 || (tiles == 128 && nk64 >= 32)) && nk64 >= 8)) return 1;
     long sp = 256 / tiles;
     if (sp > nk64 / 4) sp = nk64 / 4;
-    if (sp > 8) sp = 8;
+    // reductions over the token dimension (the weight-gradient GEMMs of the training step: K = 4096 ... 16384 tokens, a handful of
+    // output tiles) are cut as finely as it takes to put a workgroup on every CU; the short-K layers of the denoising step keep <= 8
+    static const long cap_env = getenv("WDIFF_KSPLIT_CAP") ? atol(getenv("WDIFF_KSPLIT_CAP")) : WD_MAX_KSPLIT;
+    const long cap = nk64 >= 64 ? cap_env : 8;
+    if (sp > cap) sp = cap;
     while (sp > 1 && sp * m * n > ws_floats) --sp;
     return sp > 1 ? (int)sp : 1;
 }
@@ -2228,7 +2232,7 @@ extern "C" int wd_gemm_auto_ksplit(int m, int n, int ktot, int64_t ws_floats) {
 extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
     wd_gemm_args a = *pa;
-    if (a.ksplit < 0 || a.ksplit > 16) return WD_EINVAL;
+    if (a.ksplit < 0 || a.ksplit > WD_MAX_KSPLIT) return WD_EINVAL;
     if (a.w_layout == 3) {
         // fragment-major weights (wd_gemm_pack_w): the 64 x 320 weights-to-registers kernel only
         if (a.n % 160 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160) || a.ktot % 64) return WD_EINVAL;
