@@ -402,6 +402,14 @@ int wd_transpose_planes(const void* in_hi, const void* in_lo, int in_is_f32, int
  * c channels; src = row mm (gather NULL, ntaps 1) or sample * hw_src + gather[t * hw_out + position] (zero row for -1) as in
  * wd_gemm.  The token range is cut into slices run by separate workgroups; their partial tiles go to ws
  * ([nslice][n][ntaps][c] floats) and are combined in fixed order.  Shapes: wd_dw_supported(). */
+typedef struct wd_dw_item {   /* one problem of a grouped launch (wd_dw_group): the fields of wd_dw_args that differ between layers */
+    const wd_bf16* d_hi;
+    const wd_bf16* d_lo;
+    const wd_bf16* x_hi;
+    const wd_bf16* x_lo;
+    float* grad;
+    int32_t d_ld, x_ld, grad_ld, accumulate;
+} wd_dw_item;
 typedef struct wd_dw_args {
     const wd_bf16* d_hi;
     const wd_bf16* d_lo;      /* NULL with npass 1 */
@@ -420,8 +428,19 @@ typedef struct wd_dw_args {
     int32_t dbg;
     int32_t reserved;
     void* stamps;             /* NULL (debug builds: 16 u64 of cycle sums, see csrc/wd_dw.hip) */
+    const wd_dw_item* items;  /* set by wd_dw_group (device memory); callers leave it NULL */
+    int32_t nitems;
+    int32_t reserved2;
 } wd_dw_args;
 int wd_dw(const wd_dw_args* a, void* stream);
+/* Several layers of the SAME shape (m, n, c, ntaps, hw_out, hw_src, gather, npass as in *a) in one launch: the 1x1 layers of a
+ * transformer block have four output tiles each - alone they need 64 token slices of 256 tokens to fill the chip and spend their time
+ * in prologue, epilogue and 26 MB of partial tiles; eight of them together run 2048-token slices.  items_host / items_dev: the same
+ * nitems (<= 64) records in host memory (checked here) and in device memory (read by the kernel; must stay valid until the launch has
+ * run - for a captured graph, as long as the graph).  ws: [nslice][nitems][n][ntaps][c] floats. */
+int wd_dw_group(const wd_dw_args* a, const wd_dw_item* items_host, const wd_dw_item* items_dev, int nitems, void* stream);
+int wd_dw_group_slices(int m, int n, int c, int ntaps, int nitems);
+int wd_dw_item_bytes(void);
 int wd_dw_supported(int m, int n, int c, int ntaps, int hw_out); /* m % 64, n % 160, c % 160, hw_out % 64 == 0, hw_out <= 1024 */
 int wd_dw_slices(int m, int n, int c, int ntaps);               /* the automatic nslice */
 int wd_dw_args_bytes(void);

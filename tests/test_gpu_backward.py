@@ -149,6 +149,40 @@ def test_weight_gradient_from_row_major_planes_linear(m, n, c, ld_extra, x_col, 
     assert rel_err(got.cpu(), d.double()[:, :n].t() @ x.double()[:, x_col:x_col + c]) < 2e-5
 
 
+@pytest.mark.parametrize("m,n,c,nitems,npass", [(4096, 320, 320, 6, 3), (1024, 160, 320, 3, 1), (16384, 320, 320, 8, 3)])
+def test_weight_gradient_group_of_layers_in_one_launch(m, n, c, nitems, npass):
+    """wd_dw_group: several same-shape layers (different operands, leading dimensions, accumulate flags) in one launch."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(m + n + nitems)
+    arr = (N.WdDwItem * nitems)()
+    keep, refs, grads, bases = [], [], [], []
+    for i in range(nitems):
+        d = torch.randn(m, n + 8 * (i % 3), generator=g)
+        x = torch.randn(m, c + 16 * (i % 2), generator=g)
+        dpl, xpl = planes_of(d.to(DEV)), planes_of(x.to(DEV))
+        acc = i % 2
+        grad = torch.randn(n, c, generator=g).to(DEV) if acc else torch.full((n, c), float("nan"), device=DEV)
+        bases.append(grad.clone() if acc else None)
+        arr[i].d_hi, arr[i].d_lo = dpl[0].data_ptr(), (dpl[1].data_ptr() if npass == 3 else None)
+        arr[i].x_hi, arr[i].x_lo = xpl[0].data_ptr(), (xpl[1].data_ptr() if npass == 3 else None)
+        arr[i].grad, arr[i].grad_ld, arr[i].d_ld, arr[i].x_ld, arr[i].accumulate = grad.data_ptr(), c, dpl.shape[2], xpl.shape[2], acc
+        dd = (unplanes(dpl) if npass == 3 else dpl[0].float()).double().cpu()[:, :n]
+        xx = (unplanes(xpl) if npass == 3 else xpl[0].float()).double().cpu()[:, :c]
+        refs.append(dd.t() @ xx)
+        grads.append(grad)
+        keep += [dpl, xpl]
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    ws = torch.empty(lib.wd_dw_group_slices(m, n, c, 1, nitems) * nitems * n * c, device=DEV)
+    a = N.WdDwArgs()
+    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    a.ntaps, a.hw_out, a.hw_src, a.m, a.n, a.c, a.npass = 1, 256, 256, m, n, c, npass
+    N.check(lib.wd_dw_group(C.byref(a), C.cast(arr, C.c_void_p), dev.data_ptr(), nitems, _st()), "wd_dw_group")
+    torch.cuda.synchronize()
+    for i in range(nitems):
+        got = grads[i] - bases[i] if bases[i] is not None else grads[i]
+        assert rel_err(got.cpu(), refs[i]) < (2e-5 if bases[i] is not None else 5e-6), i
+
+
 def test_weight_gradient_kernel_rejects_bad_arguments():
     lib = N.lib()
     assert not lib.wd_dw_supported(100, 320, 320, 9, 50)

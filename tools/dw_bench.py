@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--npass", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--group", type=int, default=0, help="N > 1: N layers of the shape in one wd_dw_group launch (time per layer)")
     ap.add_argument("--stamps", type=int, default=0, help="1: cycle sums of workgroup 0 (library built with -DWD_DW_STAMPS)")
     a = ap.parse_args()
     lib = N.lib()
@@ -65,6 +66,33 @@ def main():
                     print(f"   group {grp} {kn:4s} half-step: issue {t[0] / nh:7.1f}  work {t[1] / nh:7.1f}  dma wait {t[2] / nh:7.1f}  "
                           f"barrier {t[3] / nh:7.1f}   (s_memtime ticks, 100 MHz)")
             g.stamps, g.dbg = None, 0
+        if a.group > 1:
+            G = a.group
+            xs = [torch.randn(2, m, c, device=DEV).to(torch.bfloat16) for _ in range(G)]
+            ds = [torch.randn(2, m, n, device=DEV).to(torch.bfloat16) for _ in range(G)]
+            gs = [torch.empty(n, c * taps, device=DEV) for _ in range(G)]
+            arr = (N.WdDwItem * G)()
+            for i in range(G):
+                arr[i].d_hi, arr[i].d_lo, arr[i].x_hi, arr[i].x_lo = ds[i][0].data_ptr(), ds[i][1].data_ptr(), xs[i][0].data_ptr(), xs[i][1].data_ptr()
+                arr[i].grad, arr[i].grad_ld, arr[i].d_ld, arr[i].x_ld = gs[i].data_ptr(), c * taps, n, c
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+            nsg = a.nslice or lib.wd_dw_group_slices(m, n, c, taps, G)
+            wsg = torch.empty(nsg * G * n * c * taps, device=DEV)
+            g.ws, g.ws_floats, g.nslice = wsg.data_ptr(), wsg.numel(), nsg
+            run = lambda: N.check(lib.wd_dw_group(C.byref(g), C.cast(arr, C.c_void_p), dev.data_ptr(), G, st), name)  # noqa: E731
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters / G
+            gf = 2.0 * m * n * c * taps * 1e-9
+            print(f"{name:12s} group of {G}: slices={nsg:3d} wgs={(n // 160) * (c // 160) * taps * nsg * G:4d}: {us:8.1f} us per layer  {gf / us * 1e3:6.1f} TF/s algorithmic", flush=True)
+            continue
         for _ in range(3):
             N.check(lib.wd_dw(C.byref(g), st), name)
         torch.cuda.synchronize()

@@ -57,7 +57,12 @@ class WdDwArgs(C.Structure):
                 ("ws_floats", C.c_int64), ("d_ld", C.c_int32), ("x_ld", C.c_int32), ("grad_ld", C.c_int32), ("ntaps", C.c_int32),
                 ("hw_out", C.c_int32), ("hw_src", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("c", C.c_int32),
                 ("npass", C.c_int32), ("accumulate", C.c_int32), ("nslice", C.c_int32), ("dbg", C.c_int32), ("reserved", C.c_int32),
-                ("stamps", _vp)]
+                ("stamps", _vp), ("items", _vp), ("nitems", C.c_int32), ("reserved2", C.c_int32)]
+
+
+class WdDwItem(C.Structure):
+    _fields_ = [("d_hi", _vp), ("d_lo", _vp), ("x_hi", _vp), ("x_lo", _vp), ("grad", _vp), ("d_ld", C.c_int32), ("x_ld", C.c_int32),
+                ("grad_ld", C.c_int32), ("accumulate", C.c_int32)]
 
 
 _SIGS = {
@@ -66,6 +71,9 @@ _SIGS = {
     "wd_dw_supported": (_i, [_i, _i, _i, _i, _i]),
     "wd_dw_slices": (_i, [_i, _i, _i, _i]),
     "wd_dw_args_bytes": (_i, []),
+    "wd_dw_group": (_i, [C.POINTER(WdDwArgs), _vp, _vp, _i, _vp]),
+    "wd_dw_group_slices": (_i, [_i, _i, _i, _i, _i]),
+    "wd_dw_item_bytes": (_i, []),
     "wd_gemm_auto_ksplit": (_i, [_i, _i, _i, C.c_int64]),
     "wd_gemm_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "wd_ff_fused": (_i, [C.POINTER(WdFfArgs), _vp]),
@@ -182,6 +190,9 @@ def lib() -> C.CDLL:
                           "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     if l.wd_ff_args_bytes() != C.sizeof(WdFfArgs):
         raise NativeError(f"{LIB_PATH}: wd_ff_args is {l.wd_ff_args_bytes()} bytes in the library, {C.sizeof(WdFfArgs)} in "
+                          "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
+    if l.wd_dw_item_bytes() != C.sizeof(WdDwItem):
+        raise NativeError(f"{LIB_PATH}: wd_dw_item is {l.wd_dw_item_bytes()} bytes in the library, {C.sizeof(WdDwItem)} in "
                           "worddiffusion_amd/_native.py - rebuild with `python -m worddiffusion_amd.build`")
     if l.wd_dw_args_bytes() != C.sizeof(WdDwArgs):
         raise NativeError(f"{LIB_PATH}: wd_dw_args is {l.wd_dw_args_bytes()} bytes in the library, {C.sizeof(WdDwArgs)} in "

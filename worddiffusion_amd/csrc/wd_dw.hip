@@ -73,8 +73,9 @@ __device__ __forceinline__ void dw_lds_read6(const uint32_t (&ad)[6], int (&r)[6
 }
 
 template <int NPASS>
-__global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a, const int ntn, const int ntc, const int nslice) {
+__global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a0, const int ntn, const int ntc, const int nslice) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    wd_dw_args a = a0;
     constexpr int NPL = (NPASS == 1) ? 1 : 2;
     constexpr int OPB = NPL * DW_PL;       // one operand of a sub-stage
     constexpr int SLOT = 2 * OPB;          // d(out) rows, then x rows
@@ -90,15 +91,23 @@ __global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a, con
     // workgroup -> (token slice, tile): consecutive workgroups of an XCD (blockIdx % 8) share a slice, so its rows of both operands
     // are fetched into that XCD's L2 once
     const int ntile = ntn * ntc * a.ntaps;
-    const int nwg = ntile * nslice;
+    const int nprob = a.items ? a.nitems : 1;  // grouped launch: same shapes, nprob sets of operands (wd_dw_group)
+    const int nwg = ntile * nprob * nslice;
     int wg;
     {
         const int bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int sidx = __builtin_amdgcn_readfirstlane(wg / ntile);
-    int tl = wg - sidx * ntile;
+    const int sidx = __builtin_amdgcn_readfirstlane(wg / (ntile * nprob));
+    int tl = wg - sidx * ntile * nprob;
+    const int pi = __builtin_amdgcn_readfirstlane(tl / ntile);
+    tl -= pi * ntile;
+    if (a.items) {
+        const wd_dw_item it = a.items[pi];
+        a.d_hi = it.d_hi; a.d_lo = it.d_lo; a.x_hi = it.x_hi; a.x_lo = it.x_lo;
+        a.d_ld = it.d_ld; a.x_ld = it.x_ld;
+    }
     const int nb = tl % ntn;
     tl /= ntn;
     const int cb = __builtin_amdgcn_readfirstlane(tl % ntc);
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a, con
 #endif
     // ---- everybody streams the summed rows to the slice's slab
     const long kt = (long)a.ntaps * a.c;
-    float* slab = a.ws + (long)sidx * a.n * kt;
+    float* slab = a.ws + ((long)sidx * nprob + pi) * a.n * kt;
     for (int idx = tid; idx < DW_TB * (DW_TB / 4); idx += DW_NT) {
         const int row = idx / (DW_TB / 4), c4 = idx - row * (DW_TB / 4);
         const float4 v = *reinterpret_cast<const float4*>(ep + row * DW_LDE + c4 * 4);
@@ -343,36 +352,64 @@ __global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a, con
 #endif
 }
 
-// grad[n][ci * T + t] (+)= sum over slices of ws[slice][n][t * C + ci]
-__global__ void __launch_bounds__(256) wd_dw_combine_kernel(const wd_dw_args a, const int nslice) {
+// grad[n][ci * T + t] (+)= sum over slices of ws[slice][n][t * C + ci].  One workgroup per (n, 64 input channels): the slabs are
+// read tap row by tap row (64 consecutive floats), the sums turned to (ci, t) order through LDS and written as one contiguous run of
+// 64 T floats - both sides coalesced (a thread per (n, t, four ci) wrote its four results 4 T bytes apart).
+__global__ void __launch_bounds__(256) wd_dw_combine_kernel(const wd_dw_args a0, const int nslice) {
+    __shared__ float s_out[64 * 9];
+    wd_dw_args a = a0;
+    const int nprob = a.items ? a.nitems : 1, pi = blockIdx.y;
+    if (a.items) {
+        const wd_dw_item it = a.items[pi];
+        a.grad = it.grad; a.grad_ld = it.grad_ld; a.accumulate = it.accumulate;
+    }
+    const int T = a.ntaps;
+    const int nblk = (a.c + 63) >> 6;          // (c % 160 == 0 does not make c a multiple of 64: the last block may be short)
+    const int n = blockIdx.x / nblk, c0 = (blockIdx.x - n * nblk) * 64;
+    const int cw = a.c - c0 < 64 ? a.c - c0 : 64;
+    const long kt = (long)T * a.c, slab = (long)nprob * a.n * kt;
+    const float* p = a.ws + (long)pi * a.n * kt + (long)n * kt + c0;
+    for (int j = threadIdx.x; j < 64 * T; j += 256) {
+        const int t = j >> 6, cl = j & 63;
+        if (cl < cw) {
+            const float* q = p + (long)t * a.c + cl;
+            float v = q[0];
+            for (int s = 1; s < nslice; ++s) v += q[s * slab];
+            s_out[cl * T + t] = v;
+        }
+    }
+    __syncthreads();
+    float* g = a.grad + (long)n * a.grad_ld + (long)c0 * T;
+    for (int j = threadIdx.x; j < cw * T; j += 256) g[j] = a.accumulate ? g[j] + s_out[j] : s_out[j];
+}
+
+// the same for one tap (linear layers, 1x1 convolutions): no reordering, a float4 of the gradient per thread
+__global__ void __launch_bounds__(256) wd_dw_combine1_kernel(const wd_dw_args a0, const int nslice) {
+    wd_dw_args a = a0;
+    const int nprob = a.items ? a.nitems : 1, pi = blockIdx.y;
+    if (a.items) {
+        const wd_dw_item it = a.items[pi];
+        a.grad = it.grad; a.grad_ld = it.grad_ld; a.accumulate = it.accumulate;
+    }
     const int c4n = a.c >> 2;
-    const long total = (long)a.n * a.ntaps * c4n;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const long kt = (long)a.ntaps * a.c;
-    const int n = (int)(i / (a.ntaps * c4n));
-    const int rem = (int)(i - (long)n * (a.ntaps * c4n));
-    const int t = rem / c4n, ci = (rem - t * c4n) * 4;
-    const float* p = a.ws + (long)n * kt + (long)t * a.c + ci;
+    if (i >= (long)a.n * c4n) return;
+    const int n = (int)(i / c4n), ci = (int)(i - (long)n * c4n) * 4;
+    const float* p = a.ws + (long)pi * a.n * a.c + (long)n * a.c + ci;
     float4 v = *reinterpret_cast<const float4*>(p);
-    const long slab = (long)a.n * kt;
+    const long slab = (long)nprob * a.n * a.c;
     for (int s = 1; s < nslice; ++s) {
         const float4 q = *reinterpret_cast<const float4*>(p + s * slab);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
-    float* g = a.grad + (long)n * a.grad_ld + (long)ci * a.ntaps + t;
-    if (a.ntaps == 1) {
-        if (a.accumulate) {
-            const float4 o = *reinterpret_cast<const float4*>(g);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
+    float* g = a.grad + (long)n * a.grad_ld + ci;
+    if (a.accumulate) {
+        v.x += g[0]; v.y += g[1]; v.z += g[2]; v.w += g[3];
+    }
+    if (((reinterpret_cast<uintptr_t>(g)) & 15) == 0) {
         *reinterpret_cast<float4*>(g) = v;
     } else {
-        const int T = a.ntaps;
-        if (a.accumulate) {
-            v.x += g[0]; v.y += g[T]; v.z += g[2 * T]; v.w += g[3 * T];
-        }
-        g[0] = v.x; g[T] = v.y; g[2 * T] = v.z; g[3 * T] = v.w;
+        g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
     }
 }
 
@@ -408,14 +445,18 @@ int dw_launch(const wd_dw_args& a, const int nslice, hipStream_t st) {
         attr_done = true;
     }
     const int ntn = a.n / DW_TB, ntc = a.c / DW_TB;
+    const int nprob = a.items ? a.nitems : 1;
     {
-        WdLaunchScope scope(WD_CLS_DW, st, 2.0 * (double)a.m * (double)a.n * (double)a.c * (double)a.ntaps);
-        hipLaunchKernelGGL((wd_dw_kernel<NPASS>), dim3(ntn * ntc * a.ntaps * nslice), dim3(DW_NT), smem, st, a, ntn, ntc, nslice);
+        WdLaunchScope scope(WD_CLS_DW, st, 2.0 * (double)nprob * (double)a.m * (double)a.n * (double)a.c * (double)a.ntaps);
+        hipLaunchKernelGGL((wd_dw_kernel<NPASS>), dim3(ntn * ntc * a.ntaps * nprob * nslice), dim3(DW_NT), smem, st, a, ntn, ntc, nslice);
     }
     {
         WdLaunchScope scope(WD_CLS_GEMM_REDUCE, st);
-        const long items = (long)a.n * a.ntaps * (a.c >> 2);
-        hipLaunchKernelGGL(wd_dw_combine_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a, nslice);
+        if (a.ntaps == 1)
+            hipLaunchKernelGGL(wd_dw_combine1_kernel, dim3((unsigned)(((long)a.n * (a.c >> 2) + 255) / 256), nprob), dim3(256), 0, st, a,
+                               nslice);
+        else
+            hipLaunchKernelGGL(wd_dw_combine_kernel, dim3((unsigned)(a.n * ((a.c + 63) / 64)), nprob), dim3(256), 0, st, a, nslice);
     }
     return wd_check_launch();
 }
@@ -434,27 +475,62 @@ extern "C" int wd_dw_slices(int m, int n, int c, int ntaps) {
 
 extern "C" int wd_dw_args_bytes(void) { return (int)sizeof(wd_dw_args); }
 
+static int dw_check_operands(const wd_dw_args& a, const wd_bf16* d_hi, const wd_bf16* d_lo, const wd_bf16* x_hi, const wd_bf16* x_lo,
+                             const float* grad, int d_ld, int x_ld, int grad_ld) {
+    if (!d_hi || !x_hi || !grad) return WD_EINVAL;
+    if (a.npass == 3 && (!d_lo || !x_lo)) return WD_EINVAL;
+    if (d_ld < a.n || x_ld < a.c || (d_ld & 7) || (x_ld & 7) || grad_ld < a.c * a.ntaps) return WD_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(d_hi) | reinterpret_cast<uintptr_t>(d_lo) | reinterpret_cast<uintptr_t>(x_hi) |
+          reinterpret_cast<uintptr_t>(x_lo)) & 15))
+        return WD_EINVAL;
+    // (operand planes are addressed with 32-bit byte offsets below 2 GiB)
+    if ((long)a.m * d_ld * 2 >= 0x7FFFFFF0L || (long)(a.m / a.hw_out) * a.hw_src * x_ld * 2 >= 0x7FFFFFF0L) return WD_EINVAL;
+    return WD_OK;
+}
+
+static int dw_run(wd_dw_args& a, const int nprob, void* stream) {
+    if (!a.ws || (reinterpret_cast<uintptr_t>(a.ws) & 15) || (a.npass != 1 && a.npass != 3)) return WD_EINVAL;
+    if (!a.gather && (a.ntaps != 1 || a.hw_src != a.hw_out)) return WD_EINVAL;
+    if (a.gather && a.hw_src <= 0) return WD_EINVAL;
+    const int units = a.m / 64;
+    const long per_slice = (long)nprob * a.n * a.c * a.ntaps;
+    int nslice = a.nslice;
+    if (nslice <= 0) nslice = dw_auto_slices((a.n / DW_TB) * (a.c / DW_TB) * a.ntaps * nprob, units);
+    if (nslice > units) nslice = units;
+    while (nslice > 1 && nslice * per_slice > a.ws_floats) --nslice;
+    if (nslice * per_slice > a.ws_floats) return WD_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return a.npass == 3 ? dw_launch<3>(a, nslice, st) : dw_launch<1>(a, nslice, st);
+}
+
+extern "C" int wd_dw_group_slices(int m, int n, int c, int ntaps, int nitems) {
+    if (m < 128 || n < DW_TB || c < DW_TB || nitems < 1) return 1;
+    return dw_auto_slices((n / DW_TB) * (c / DW_TB) * ntaps * nitems, m / 64);
+}
+
+extern "C" int wd_dw_item_bytes(void) { return (int)sizeof(wd_dw_item); }
+
+extern "C" int wd_dw_group(const wd_dw_args* pa, const wd_dw_item* items_host, const wd_dw_item* items_dev, int nitems, void* stream) {
+    if (!pa || !items_host || !items_dev || nitems < 1 || nitems > 64) return WD_EINVAL;
+    wd_dw_args a = *pa;
+    if (!wd_dw_supported(a.m, a.n, a.c, a.ntaps, a.hw_out)) return WD_EINVAL;
+    for (int i = 0; i < nitems; ++i) {
+        const wd_dw_item& it = items_host[i];
+        const int rc = dw_check_operands(a, it.d_hi, it.d_lo, it.x_hi, it.x_lo, it.grad, it.d_ld, it.x_ld, it.grad_ld);
+        if (rc != WD_OK) return rc;
+    }
+    a.items = items_dev;
+    a.nitems = nitems;
+    return dw_run(a, nitems, stream);
+}
+
 extern "C" int wd_dw(const wd_dw_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
     wd_dw_args a = *pa;
     if (!wd_dw_supported(a.m, a.n, a.c, a.ntaps, a.hw_out)) return WD_EINVAL;
-    if (!a.d_hi || !a.x_hi || !a.grad || !a.ws || (a.npass != 1 && a.npass != 3)) return WD_EINVAL;
-    if (a.npass == 3 && (!a.d_lo || !a.x_lo)) return WD_EINVAL;
-    if (a.d_ld < a.n || a.x_ld < a.c || (a.d_ld & 7) || (a.x_ld & 7) || a.grad_ld < a.c * a.ntaps) return WD_EINVAL;
-    if (!a.gather && (a.ntaps != 1 || a.hw_src != a.hw_out)) return WD_EINVAL;
-    if (a.gather && a.hw_src <= 0) return WD_EINVAL;
-    if (((reinterpret_cast<uintptr_t>(a.d_hi) | reinterpret_cast<uintptr_t>(a.d_lo) | reinterpret_cast<uintptr_t>(a.x_hi) |
-          reinterpret_cast<uintptr_t>(a.x_lo) | reinterpret_cast<uintptr_t>(a.ws)) & 15) ||
-        (a.ntaps == 1 && ((reinterpret_cast<uintptr_t>(a.grad) & 15) || (a.grad_ld & 3))))
-        return WD_EINVAL;
-    // (operand planes are addressed with 32-bit byte offsets below 2 GiB)
-    if ((long)a.m * a.d_ld * 2 >= 0x7FFFFFF0L || (long)(a.m / a.hw_out) * a.hw_src * a.x_ld * 2 >= 0x7FFFFFF0L) return WD_EINVAL;
-    const int units = a.m / 64;
-    int nslice = a.nslice;
-    if (nslice <= 0) nslice = dw_auto_slices((a.n / DW_TB) * (a.c / DW_TB) * a.ntaps, units);
-    if (nslice > units) nslice = units;
-    while (nslice > 1 && (long)nslice * a.n * a.c * a.ntaps > a.ws_floats) --nslice;
-    if ((long)nslice * a.n * a.c * a.ntaps > a.ws_floats) return WD_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    return a.npass == 3 ? dw_launch<3>(a, nslice, st) : dw_launch<1>(a, nslice, st);
+    const int rc = dw_check_operands(a, a.d_hi, a.d_lo, a.x_hi, a.x_lo, a.grad, a.d_ld, a.x_ld, a.grad_ld);
+    if (rc != WD_OK) return rc;
+    a.items = nullptr;
+    a.nitems = 0;
+    return dw_run(a, 1, stream);
 }

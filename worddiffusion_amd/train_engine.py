@@ -63,6 +63,9 @@ class TrainEngine(UNetEngine):
         self.use_wdirect = os.environ.get("WDIFF_TRAIN_WDIRECT", "0") != "0"
         self.fuse_ff = self.fuse_proj = False
         self.fuse_gn_in = 0
+        self.use_dw = os.environ.get("WDIFF_TRAIN_DW", "1") != "0"  # weight gradients through wd_dw (csrc/wd_dw.hip) where it applies
+        self.dw_group_max = int(os.environ.get("WDIFF_DW_GROUP", "8"))  # single-tap layers of one shape per grouped launch (1: off)
+        self._dw_pending: Dict[tuple, list] = {}
         self._tplans: Dict[tuple, TrainPlan] = {}
         self._grad: Dict[int, torch.Tensor] = {}     # id(param) -> gradient buffer (possibly a view into a group)
         self._params: Dict[int, torch.nn.Parameter] = {}
@@ -287,6 +290,44 @@ class TrainEngine(UNetEngine):
         self._cur_plan.keep.append(a)
         ops.append((self.lib.wd_gemm, (C.byref(a),), what))
 
+    def _dw(self, ops, what, dpl, d_ld, planes, col_off, c, ftab, ntaps, hw_out, hw_src, M, n, out: torch.Tensor, out_ld, acc):
+        a = N.WdDwArgs()
+        a.d_hi, a.d_lo = dpl[0].data_ptr(), (dpl[1].data_ptr() if self.npass == 3 else None)
+        a.x_hi = planes[0].data_ptr() + 2 * col_off
+        a.x_lo = planes[1].data_ptr() + 2 * col_off if self.npass == 3 else None
+        a.gather = _ptr(ftab)
+        a.grad, a.grad_ld, a.ws, a.ws_floats = out.data_ptr(), out_ld, self._ws.data_ptr(), self._ws.numel()
+        a.d_ld, a.x_ld, a.ntaps, a.hw_out, a.hw_src = d_ld, planes.shape[2], ntaps, hw_out, hw_src
+        a.m, a.n, a.c, a.npass, a.accumulate, a.nslice = M, n, c, self.npass, int(bool(acc)), 0
+        self._cur_plan.keep.append(a)
+        ops.append((self.lib.wd_dw, (C.byref(a),), what))
+
+    def _flush_dw(self, P):
+        """Emits the weight-gradient launches put off by _bwd_linear: layers of one shape as ONE grouped wd_dw_group launch."""
+        pend, self._dw_pending = self._dw_pending, {}
+        for (M, n, c, hw), items in pend.items():
+            for lo in range(0, len(items), self.dw_group_max):
+                grp = items[lo:lo + self.dw_group_max]
+                if len(grp) == 1:
+                    it = grp[0]
+                    self._dw(P.bwd, it["what"], it["dpl"], it["d_ld"], it["planes"], it["col_off"], c, None, 1, hw, hw, M, n,
+                             it["wg"], it["out_ld"], self._pacc(it["wg"]))
+                    continue
+                arr = (N.WdDwItem * len(grp))()
+                for i, it in enumerate(grp):
+                    arr[i].d_hi, arr[i].d_lo = it["dpl"][0].data_ptr(), (it["dpl"][1].data_ptr() if self.npass == 3 else None)
+                    arr[i].x_hi = it["planes"][0].data_ptr() + 2 * it["col_off"]
+                    arr[i].x_lo = it["planes"][1].data_ptr() + 2 * it["col_off"] if self.npass == 3 else None
+                    arr[i].grad, arr[i].grad_ld = it["wg"].data_ptr(), it["out_ld"]
+                    arr[i].d_ld, arr[i].x_ld, arr[i].accumulate = it["d_ld"], it["planes"].shape[2], self._pacc(it["wg"])
+                dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                a = N.WdDwArgs()
+                a.ws, a.ws_floats = self._ws.data_ptr(), self._ws.numel()
+                a.ntaps, a.hw_out, a.hw_src, a.m, a.n, a.c, a.npass, a.nslice = 1, hw, hw, M, n, c, self.npass, 0
+                P.keep += [arr, dev, a]
+                P.bwd.append((self.lib.wd_dw_group, (C.byref(a), C.cast(arr, C.c_void_p), dev.data_ptr(), len(grp)),
+                              "dW group: " + ", ".join(it["what"] for it in grp)))
+
     def _bwd_linear(self, P, what, dout: torch.Tensor, M, n, hw_out, segs, bias=(), film_off=None, npad=None):
         """Backward of out[M, n] = sum_seg gather(planes_seg) . W_seg^T + bias (+ FiLM row vector).
 
@@ -301,9 +342,26 @@ class TrainEngine(UNetEngine):
         mpad = _rup(M, 64)
         lo_ok = self.npass == 3
         need_dx = any(s.get("dx") for s in segs)
-        need_dw = any(s.get("wgrad") is not None or s.get("wgrad_packed") is not None for s in segs)
+        # weight gradients straight from the row-major planes (wd_dw: transposed LDS reads) wherever the shape allows; the rest goes
+        # through transposed copies of both operands and wd_gemm
+        hw_dw = hw_out if (hw_out % 64 == 0 and M % hw_out == 0) else 64
+        for s in segs:
+            s["_dw"] = bool(self.use_dw and s.get("wgrad") is not None and npad % 8 == 0 and s["planes"].shape[2] % 8 == 0 and
+                            s.get("col_off", 0) % 8 == 0 and (s.get("ftab") is not None or s["ntaps"] == 1) and
+                            lib.wd_dw_supported(M, n, s["c"], s["ntaps"], hw_out if s.get("ftab") is not None else hw_dw) and
+                            lib.wd_dw_slices(M, n, s["c"], s["ntaps"]) * n * s["c"] * s["ntaps"] <= self._ws.numel())
+        need_dw = any((s.get("wgrad") is not None and not s["_dw"]) or s.get("wgrad_packed") is not None for s in segs)
+        need_dpl = need_dx or any(s["_dw"] for s in segs)
+        # single-tap layers wait for the others of their shape (one grouped launch at the end of the block's backward, _flush_dw):
+        # their d(out) planes then need a buffer of their own
+        for s in segs:
+            s["_defer"] = bool(s["_dw"] and self.dw_group_max > 1 and s["ntaps"] == 1 and s.get("ftab") is None and
+                               self.lib.wd_dw_group_slices(M, n, s["c"], 1, 2) * 2 * n * s["c"] <= self._ws.numel())
         dpl = doutT = colpart = None
-        if need_dx:
+        if need_dpl and any(s["_defer"] for s in segs):
+            dpl = torch.empty(2, M, npad, dtype=torch.bfloat16, device=self.device)
+            P.keep.append(dpl)
+        elif need_dpl:
             dpl = self._scratch("dpl", 2 * self._max_dpl, torch.bfloat16)[: 2 * M * npad].view(2, M, npad)
         if need_dw:
             doutT = self._scratch("doutT", 2 * self._max_doutT, torch.bfloat16)[: 2 * n * mpad].view(2, n, mpad)
@@ -318,10 +376,10 @@ class TrainEngine(UNetEngine):
             else:
                 colpart = self._scratch("colpart", self._max_colpart, torch.float32)
             assert (mpad // 64) * n <= colpart.numel(), what
-        if need_dx or need_dw or fuse_cs:
-            # one pass over d(output): row-major planes (data gradient), transposed planes (weight gradient), column sums
-            ops.append((lib.wd_dout_prep, (dout.data_ptr(), ldd, M, n, npad, mpad, _ptr(dpl[0]) if need_dx else None,
-                                           (_ptr(dpl[1]) if lo_ok else None) if need_dx else None,
+        if need_dpl or need_dw or fuse_cs:
+            # one pass over d(output): row-major planes (data gradient, wd_dw), transposed planes (wd_gemm weight gradient), column sums
+            ops.append((lib.wd_dout_prep, (dout.data_ptr(), ldd, M, n, npad, mpad, _ptr(dpl[0]) if need_dpl else None,
+                                           (_ptr(dpl[1]) if lo_ok else None) if need_dpl else None,
                                            _ptr(doutT[0]) if need_dw else None, _ptr(doutT[1]) if need_dw else None,
                                            _ptr(colpart)), what + ":prep(dout)"))
         for si, s in enumerate(segs):
@@ -336,8 +394,17 @@ class TrainEngine(UNetEngine):
             if wg is None and wgp is None:
                 continue
             k = ntaps * c
-            xT = self._scratch("xT", 2 * self._max_xT, torch.bfloat16)[: 2 * k * mpad].view(2, k, mpad)
             ftab = s.get("ftab")
+            if s["_defer"]:
+                self._dw_pending.setdefault((M, n, c, hw_dw), []).append(
+                    dict(what=f"{what}:dW{si}", dpl=dpl, d_ld=npad, planes=planes, col_off=s.get("col_off", 0), wg=wg, out_ld=k))
+                continue
+            if s["_dw"]:
+                self._dw(ops, f"{what}:dW{si}", dpl, npad, planes, s.get("col_off", 0), c, ftab, ntaps,
+                         hw_out if ftab is not None else hw_dw, s["hw_src"] if ftab is not None else hw_dw, M, n, wg, k,
+                         self._pacc(wg))
+                continue
+            xT = self._scratch("xT", 2 * self._max_xT, torch.bfloat16)[: 2 * k * mpad].view(2, k, mpad)
             ops.append((lib.wd_transpose_planes,
                         (planes[0].data_ptr() + 2 * s.get("col_off", 0), planes[1].data_ptr() + 2 * s.get("col_off", 0), 0,
                          planes.shape[2], c, _ptr(ftab), ntaps, hw_out if ftab is not None else 0,
@@ -907,6 +974,7 @@ class TrainEngine(UNetEngine):
         self._closure = 1
         for fn in reversed(self._tape):
             fn()
+            self._flush_dw(P)
             want = (first_plan and self.nbuckets > 1 and len(cuts_seen) < self.nbuckets - 1 and
                     self._arena_used >= (len(cuts_seen) + 1) * total // self.nbuckets) or \
                    (not first_plan and self._closure in self._cut_closures)
@@ -977,6 +1045,7 @@ class TrainEngine(UNetEngine):
                                    dx=[(de, cd, 0, 0, cd)], dx_rows=B * n_tok, dx_hw=n_tok)], bias=[qkv_b])
             bops.append((lib.wd_embedding_bwd, (ids.data_ptr(), i64, B * n_tok, de.data_ptr(), cd, we.embedding.weight.shape[0], cd,
                                                 dtab.data_ptr(), self._pacc(dtab)), "word_emb.embedding:bwd"))
+        self._flush_dw(P)
         self._flush_deferred(P)
         self._tape = []
         # arena prefix that is final at each cut: the longest prefix (in carve order) of buffers whose last writer is a closure
