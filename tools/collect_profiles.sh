@@ -35,5 +35,13 @@ VARIANT=phosc python3 $ROOT/tools/step_ops.py > $OUT/${TAG}_step_ops_phosc.txt 2
 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl -o t -- python3 $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --train-steps 0 --no-vae --no-roofline --no-full-call --no-phosc > $OUT/${TAG}_tl.log 2>&1
 python3 $ROOT/tools/step_timeline.py $(find $OUT/${TAG}_tl -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline.txt
 rm -rf $OUT/${TAG}_tl
+# the training step: per-launch table, the weight-gradient kernel alone, MFMA-busy counters of its kernels
+python3 $ROOT/tools/train_ops.py > $OUT/${TAG}_train_ops.txt 2>/dev/null
+python3 $ROOT/tools/dw_bench.py > $OUT/${TAG}_dw_bench.txt 2>/dev/null
+python3 $ROOT/tools/dw_bench.py --shape lin8x32,skip8x32 --group 6 >> $OUT/${TAG}_dw_bench.txt 2>/dev/null
+STEPS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma_train -o m -- python3 $ROOT/tools/train_prof.py > $OUT/${TAG}_pmc_mfma_train.log 2>&1
+M=$(find $OUT/${TAG}_pmc_mfma_train -name "*counter_collection.csv" | head -1)
+python3 $ROOT/tools/pmc_mfma.py "$M" > $OUT/${TAG}_pmc_mfma_util_train.json
+rm -rf $OUT/${TAG}_pmc_mfma_train
 echo "[collect] done"
 ls $OUT | grep "^${TAG}_"
