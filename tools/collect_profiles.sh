@@ -24,7 +24,10 @@ python3 $ROOT/tools/pmc_mfma.py "$M" > $OUT/${TAG}_pmc_mfma_util.json || exit 8
 F=$(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
 python3 $ROOT/tools/pmc_traffic.py "$F" "$W" > $OUT/${TAG}_pmc_hbm_traffic.json || exit 6
-find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train -name "*kernel_stats.csv" | while read f; do cp "$f" $OUT/${TAG}_$(basename $(dirname $(dirname "$f")) | sed "s/${TAG}_prof_//")_kernel_stats.csv 2>/dev/null; done
+for d in bench train; do
+    f=$(find $OUT/${TAG}_prof_$d -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && cp "$f" $OUT/${TAG}_${d}_kernel_stats.csv
+done
 # the raw traces are large: keep the summaries only
 find $OUT/${TAG}_prof_bench $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete
 find $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" -delete
