@@ -464,6 +464,14 @@ int wd_gn_bwd_apply(const float* x, int ld, const float* dz, int dz_ld, int dz_o
                     const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off, float eps,
                     int silu, const float* sums, float* dx, int dx_ld, int accumulate, void* stream);
 
+/* Both passes in one launch: a workgroup keeps its (sample, 40 channels = whole groups) tile of dy and xhat in LDS, so x and dz are
+ * read once.  sums: [b][2][c] (the layout of wd_gn_bwd_stats with one chunk).  Shapes: wd_gn_bwd_fused_supported (40 | c, cpg | 40,
+ * the hw x 40 tile pair within LDS: hw <= 448); everything else as wd_gn_bwd_stats / _apply. */
+int wd_gn_bwd_fused_supported(int hw, int c, int cpg);
+int wd_gn_bwd_fused(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c, int cpg,
+                    const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off, float eps,
+                    int silu, float* sums, float* dx, int dx_ld, int accumulate, void* stream);
+
 /* LayerNorm backward (nn.LayerNorm of BasicTransformerBlock, unet.py:314-316): dx (+=), and colpart[blk][2][c] (blk < wd_layernorm_bwd_nblk(rows)) whose column sums are
  * [d gamma | d beta]. */
 int wd_layernorm_bwd_nblk(int rows);

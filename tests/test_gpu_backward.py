@@ -213,7 +213,8 @@ def test_transpose_planes_and_colsum():
     assert max_rel(out.cpu()[:, :100], ref) < 1e-6 and float((out.cpu()[:, 100:] - 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,hw,cs,silu,eps", [(3, 256, (320,), 1, 1e-5), (2, 64, (320, 320), 1, 1e-5), (2, 32, (64,), 0, 1e-6)])
+@pytest.mark.parametrize("B,hw,cs,silu,eps", [(3, 256, (320,), 1, 1e-5), (2, 64, (320, 320), 1, 1e-5), (2, 32, (64,), 0, 1e-6),
+                                               (2, 256, (320, 320), 0, 1e-6)])
 def test_groupnorm_backward(B, hw, cs, silu, eps):
     lib = N.lib()
     g = torch.Generator().manual_seed(hw + sum(cs))
@@ -254,6 +255,24 @@ def test_groupnorm_backward(B, hw, cs, silu, eps):
         flat = dgam.reshape(-1).cpu()
         assert max_rel(flat[off:off + c], beta.grad[off:off + c]) < 3e-5
         assert max_rel(flat[off + c:off + 2 * c], gamma.grad[off:off + c]) < 3e-5
+        # the one-pass form: same dx, the same per-channel sums with one chunk per sample
+        if lib.wd_gn_bwd_fused_supported(hw, c, cpg):
+            sums1 = torch.full((B, 1, 2, c), float("nan"), device=DEV)
+            dx1 = torch.ones(B * hw, c, device=DEV)
+            N.check(lib.wd_gn_bwd_fused(xd.data_ptr(), c, dzd.data_ptr(), ctot, off, B, hw, c, cpg, part.data_ptr(), nck, c // 32,
+                                        gd.data_ptr(), bd.data_ptr(), off, eps, silu, sums1.data_ptr(), dx1.data_ptr(), c, 1, _st()),
+                    "bwd fused")
+            torch.cuda.synchronize()
+            assert max_rel(dx1.cpu() - 1.0, xref.grad) < 3e-5
+            assert max_rel(sums1.sum((0, 1)).cpu(), sums.sum((0, 1)).cpu()) < 1e-5
+            dx0 = torch.full((B * hw, c), float("nan"), device=DEV)
+            N.check(lib.wd_gn_bwd_fused(xd.data_ptr(), c, dzd.data_ptr(), ctot, off, B, hw, c, cpg, part.data_ptr(), nck, c // 32,
+                                        gd.data_ptr(), bd.data_ptr(), off, eps, silu, sums1.data_ptr(), dx0.data_ptr(), c, 0, _st()),
+                    "bwd fused (assign)")
+            torch.cuda.synchronize()
+            assert max_rel(dx0.cpu(), xref.grad) < 3e-5
+        else:
+            assert c % 40 != 0 or 40 % cpg != 0
         off += c
         dgam.zero_()
         if len(cs) > 1:

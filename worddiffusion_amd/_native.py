@@ -136,6 +136,8 @@ _SIGS = {
     "wd_gn_bwd_nchunk": (_i, [_i]),
     "wd_gn_bwd_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "wd_gn_bwd_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _i, _i, _vp]),
+    "wd_gn_bwd_fused_supported": (_i, [_i, _i, _i]),
+    "wd_gn_bwd_fused": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _i, _i, _vp]),
     "wd_layernorm_bwd_nblk": (_i, [_i]),
     "wd_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _vp]),
     "wd_attention_bwd_small_nwg": (_i, [_i, _i, _i, _i]),

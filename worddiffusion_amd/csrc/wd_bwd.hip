@@ -903,6 +903,155 @@ extern "C" int wd_colsum(const float* x, int ld, int rows, int c, int seg, float
     return wd_check_launch();
 }
 
+// ---- GroupNorm (+SiLU) backward in ONE pass over the tensors: a workgroup owns (sample, GF_CB channels = whole groups), keeps
+// dy (d z through the SiLU) and xhat of its hw x GF_CB tile in LDS (320 B per token: 80 KB at 8 x 32), sums them per channel in a
+// fixed order, derives the group means and writes dx - x and dz are read once (42 MB + 21 MB written for a 320-channel 8 x 32 map
+// at batch 64 instead of 84 + 21 in the two-pass form), one launch instead of two.  sums[b][0][2][c] as pass 1 of the two-pass form
+// writes them with one chunk.
+constexpr int GF_CB = 40;      // channels per workgroup (4 groups of 10, 2 of 20, 1 of 40)
+constexpr int GF_NT = 256;
+constexpr int GF_Q = GF_CB / 4;            // channel quads
+constexpr int GF_RPP = GF_NT / GF_Q;       // token lanes (25; 250 threads work)
+__global__ void __launch_bounds__(GF_NT) gn_bwd_fused_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dz, int dz_ld,
+                                                            int dz_off, int hw, int c, int cpg, const double* __restrict__ part,
+                                                            int nchunk_f, int part_cpg, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int c_off, float eps, int silu,
+                                                            float* __restrict__ sums, float* __restrict__ dx, int dx_ld, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_dy = reinterpret_cast<float*>(smem);           // [hw][GF_CB]
+    float* s_xh = s_dy + (long)hw * GF_CB;                    // [hw][GF_CB]
+    float* s_red = s_xh + (long)hw * GF_CB;                   // [GF_RPP][2][GF_CB]
+    __shared__ float s_mean[8], s_rstd[8], s_m1[8], s_m2[8];
+    __shared__ float s_s1[GF_CB], s_s2[GF_CB];
+    const int b = blockIdx.y, c0 = blockIdx.x * GF_CB;
+    const int gpb = GF_CB / cpg, g0 = c0 / cpg;               // groups of this workgroup
+    const int tid = threadIdx.x;
+    if (tid < gpb) {
+        const int g = g0 + tid;
+        const int ratio = cpg / part_cpg, ngs = c / part_cpg;
+        double ds = 0.0, dq = 0.0;
+        for (int k = 0; k < nchunk_f; ++k) {
+            const double* p = part + (((long)b * nchunk_f + k) * ngs + g * ratio) * 2;
+            for (int q = 0; q < ratio; ++q) {
+                ds += p[2 * q];
+                dq += p[2 * q + 1];
+            }
+        }
+        const double n = (double)hw * cpg, mean = ds / n;
+        double var = dq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int tl = tid / GF_Q, cx = (tid - tl * GF_Q) * 4;   // token lane, first channel of the quad (inside the block)
+    const bool work = tl < GF_RPP;
+    float mean[4], rstd[4], gam[4], bet[4];
+    int gl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gl[k] = (cx + k) / cpg;
+        mean[k] = s_mean[gl[k]];
+        rstd[k] = s_rstd[gl[k]];
+        gam[k] = gamma[c_off + c0 + cx + k];
+        bet[k] = beta[c_off + c0 + cx + k];
+    }
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    if (work) {
+        for (int t = tl; t < hw; t += GF_RPP) {
+            const long row = (long)b * hw + t;
+            const float4 xv = *reinterpret_cast<const float4*>(x + row * ld + c0 + cx);
+            const float4 dv = *reinterpret_cast<const float4*>(dz + row * dz_ld + dz_off + c0 + cx);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds4[4] = {dv.x, dv.y, dv.z, dv.w};
+            float dy[4], xh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xh[k] = (xs[k] - mean[k]) * rstd[k];
+                dy[k] = ds4[k];
+                if (silu) dy[k] *= silu_grad(gam[k] * xh[k] + bet[k]);
+                a1[k] += dy[k];
+                a2[k] += dy[k] * xh[k];
+            }
+            *reinterpret_cast<float4*>(s_dy + (long)t * GF_CB + cx) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+            *reinterpret_cast<float4*>(s_xh + (long)t * GF_CB + cx) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_red[(tl * 2 + 0) * GF_CB + cx + k] = a1[k];
+            s_red[(tl * 2 + 1) * GF_CB + cx + k] = a2[k];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * GF_CB) {  // per-channel sums over the token lanes, fixed order
+        const int which = tid / GF_CB, cc = tid - which * GF_CB;
+        double t = 0.0;
+        for (int k = 0; k < GF_RPP; ++k) t += (double)s_red[(k * 2 + which) * GF_CB + cc];
+        (which ? s_s2 : s_s1)[cc] = (float)t;
+        sums[((long)b * 2 + which) * c + c0 + cc] = (float)t;  // [b][1 chunk][{sum dy, sum dy*xhat}][c]
+    }
+    __syncthreads();
+    if (tid < gpb) {
+        double m1 = 0.0, m2 = 0.0;
+        for (int cc = tid * cpg; cc < (tid + 1) * cpg; ++cc) {
+            m1 += (double)gamma[c_off + c0 + cc] * (double)s_s1[cc];
+            m2 += (double)gamma[c_off + c0 + cc] * (double)s_s2[cc];
+        }
+        const double n = (double)hw * cpg;
+        s_m1[tid] = (float)(m1 / n);
+        s_m2[tid] = (float)(m2 / n);
+    }
+    __syncthreads();
+    if (!work) return;
+    float m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m1[k] = s_m1[gl[k]];
+        m2[k] = s_m2[gl[k]];
+    }
+    for (int t = tl; t < hw; t += GF_RPP) {
+        const float4 dv = *reinterpret_cast<const float4*>(s_dy + (long)t * GF_CB + cx);
+        const float4 hv = *reinterpret_cast<const float4*>(s_xh + (long)t * GF_CB + cx);
+        const float dy[4] = {dv.x, dv.y, dv.z, dv.w}, xh[4] = {hv.x, hv.y, hv.z, hv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (gam[k] * dy[k] - m1[k] - xh[k] * m2[k]);
+        float4* op = reinterpret_cast<float4*>(dx + ((long)b * hw + t) * dx_ld + c0 + cx);
+        float4 r = make_float4(o[0], o[1], o[2], o[3]);
+        if (accumulate) {
+            const float4 old = *op;
+            r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+        }
+        *op = r;
+    }
+}
+
+extern "C" int wd_gn_bwd_fused_supported(int hw, int c, int cpg) {
+    return hw > 0 && c > 0 && cpg > 0 && c % GF_CB == 0 && GF_CB % cpg == 0 && GF_CB / cpg <= 8 && c % cpg == 0 && c / cpg <= 32 &&
+           (long)hw * GF_CB * 8 + GF_RPP * 2 * GF_CB * 4 <= 150 * 1024;
+}
+
+extern "C" int wd_gn_bwd_fused(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c, int cpg,
+                               const double* part, int nchunk_f, int part_cpg, const float* gamma, const float* beta, int c_off,
+                               float eps, int silu, float* sums, float* dx, int dx_ld, int accumulate, void* stream) {
+    if (!x || !dz || !part || !gamma || !beta || !sums || !dx || batch <= 0) return WD_EINVAL;
+    if (!wd_gn_bwd_fused_supported(hw, c, cpg)) return WD_EINVAL;
+    if (ld % 4 || dz_ld % 4 || dz_off % 4 || dx_ld % 4 || c_off % 4 || cpg % part_cpg) return WD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx)) & 15) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int smem = hw * GF_CB * 8 + GF_RPP * 2 * GF_CB * 4;
+    static int attr_max = 0;
+    if (smem > attr_max) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess)
+            return WD_ELAUNCH;
+        attr_max = smem;
+    }
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(c / GF_CB, batch), dim3(GF_NT), smem, st, x, ld, dz, dz_ld, dz_off, hw, c, cpg, part,
+                       nchunk_f, part_cpg, gamma, beta, c_off, eps, silu, sums, dx, dx_ld, accumulate);
+    return wd_check_launch();
+}
+
 extern "C" int wd_gn_bwd_nchunk(int hw) { return (hw + GB_TOK - 1) / GB_TOK; }
 
 extern "C" int wd_gn_bwd_stats(const float* x, int ld, const float* dz, int dz_ld, int dz_off, int batch, int hw, int c,

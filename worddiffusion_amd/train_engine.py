@@ -64,6 +64,7 @@ class TrainEngine(UNetEngine):
         self.fuse_ff = self.fuse_proj = False
         self.fuse_gn_in = 0
         self.use_dw = os.environ.get("WDIFF_TRAIN_DW", "1") != "0"  # weight gradients through wd_dw (csrc/wd_dw.hip) where it applies
+        self.fuse_gn_bwd = os.environ.get("WDIFF_FUSE_GN_BWD", "1") != "0"  # GroupNorm backward in one pass (wd_gn_bwd_fused)
         self.dw_group_max = int(os.environ.get("WDIFF_DW_GROUP", "8"))  # single-tap layers of one shape per grouped launch (1: off)
         self._dw_pending: Dict[tuple, list] = {}
         self._tplans: Dict[tuple, TrainPlan] = {}
@@ -450,7 +451,9 @@ class TrainEngine(UNetEngine):
         gw, gb = self._w[self._gn_names[id(gn)] + ".g"], self._w[self._gn_names[id(gn)] + ".b"]
         pair = self._ppair(bet, gam)  # [d beta | d gamma], the order of the planar sums
         dbet, dgam = pair[0], pair[1]
-        nb = lib.wd_gn_bwd_nchunk(hw)
+        # one pass (the workgroup keeps its tile of dy / xhat in LDS) where the shape allows, else statistics pass + apply pass
+        fused = self.fuse_gn_bwd and all(lib.wd_gn_bwd_fused_supported(hw, s.c, cpg) for s in srcs)
+        nb = 1 if fused else lib.wd_gn_bwd_nchunk(hw)
         off = 0
         accp = self._pacc(pair)
         for s in srcs:
@@ -458,9 +461,12 @@ class TrainEngine(UNetEngine):
             sums = self._f32(P, B, nb, 2, s.c)
             common = (s.t.data_ptr(), s.c, dz.data_ptr(), ctot, off, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc,
                       gw.data_ptr(), gb.data_ptr(), off, eps, int(silu), sums.data_ptr())
-            ops.append((lib.wd_gn_bwd_stats, common, what + ":stats"))
             g, acc = self._gacc(P, s)
-            ops.append((lib.wd_gn_bwd_apply, common + (g.data_ptr(), s.c, acc), what + ":apply"))
+            if fused:
+                ops.append((lib.wd_gn_bwd_fused, common + (g.data_ptr(), s.c, acc), what + ":bwd"))
+            else:
+                ops.append((lib.wd_gn_bwd_stats, common, what + ":stats"))
+                ops.append((lib.wd_gn_bwd_apply, common + (g.data_ptr(), s.c, acc), what + ":apply"))
             if len(srcs) == 1:
                 self._param_colsum(ops, what + ":dbeta|dgamma", sums.data_ptr(), 2 * s.c, B * nb, 2 * s.c, pair.data_ptr(), accp)
             else:
