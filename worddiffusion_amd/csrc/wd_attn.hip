@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256) attn_small_kernel(const float* __restrict
 typedef __attribute__((ext_vector_type(8))) __bf16 fa_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float fa_f32x16;
 constexpr int FA_KB = 64;    // keys per LDS block (two 32-key MFMA sub-blocks)
+constexpr float FA_LAZY = 8.0f;  // log2 headroom of the lazily updated softmax maximum (attn_mfma_kernel)
 constexpr int FA_QB = 128;   // queries per workgroup
 
 __device__ __forceinline__ void fa_split8(const float* f, fa_bf16x8& hi, fa_bf16x8& lo) {
@@ -382,26 +383,35 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const float* __restrict_
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
             }
-            float bm = -1e30f;
+            if (k0 + 32 > nk) {  // (uniform) only the last sub-block has keys to mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= nk) s[r] = -1e30f;
-                bm = fmaxf(bm, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= nk) s[r] = -1e30f;
+                }
             }
+            float bm = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, s[r]);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-            const float m_new = fmaxf(m, bm);
-            const float alpha = exp2f(m - m_new);
-            m = m_new;
-            lsum *= alpha;
+            // Lazy rescale: the running maximum only moves when some query of the wave outgrew it by more than 2^FA_LAZY (the
+            // exponentials then stay below 2^FA_LAZY, harmless in fp32 and in the split-bf16 product; the final division by lsum
+            // uses the same reference, so the softmax is unchanged) - after the first blocks that is almost never, and the 48
+            // multiplications of the output accumulators per sub-block go away with it.
+            if (__any(bm > m + FA_LAZY)) {
+                const float m_new = fmaxf(m, bm);
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                m = m_new;
+                lsum *= alpha;
 #pragma unroll
-            for (int t = 0; t < DVT; ++t)
+                for (int t = 0; t < DVT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = exp2f(s[r] - m_new);
+                p[r] = __builtin_amdgcn_exp2f(s[r] - m);   // (raw v_exp_f32: arguments <= FA_LAZY, large negatives flush to 0)
                 lsum += p[r];
             }
 #pragma unroll
