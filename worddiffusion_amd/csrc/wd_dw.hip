@@ -27,7 +27,8 @@
 //   * the token slices' partial tiles go to the workspace in [slice][n][tap][ci] order (coalesced), and one small combine launch
 //     sums them in fixed order into the OIHW gradient (+ the accumulation into a gradient that already holds a value).
 //     No atomics: a replayed step is bit-identical.
-// Per sub-stage and CU: 41 KB through the vector memory path (measured ceiling ~35 B/clk per CU) against 1200 MFMA cycles.
+// Per sub-stage and CU: 41 KB through the vector memory path (40 kilobyte instructions at ~25 cycles each, ~1000 cycles of the
+// reading group's half-step, + ~450 of transposed reads) against 1220 cycles of MFMAs in the other group.
 #include "wd_gemm_epi.h"
 
 namespace {
@@ -324,8 +325,7 @@ __global__ void __launch_bounds__(DW_NT, 1) wd_dw_kernel(const wd_dw_args a0, co
             hs_read(kk);
             hs_mfma(kk);
         }
-        // (every DMA has landed: the last live batch was waited for, the no-op batches behind it write nothing... they do write
-        // zeros: hs_mfma's vmcnt(0) covers them as well)
+        // (hs_mfma's vmcnt(0) covered this group's trailing no-op DMA as well: nothing lands in what becomes the image)
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
