@@ -350,11 +350,30 @@ def train_leg(dev, precision, B, steps, warmup, rank, world, barrier, wdist):
         torch.cuda.synchronize()
         pms = (C.c_double * N.NCLASS)()
         cnt = (C.c_int64 * N.NCLASS)()
-        fl = C.c_double()
-        lib.wd_prof_collect(pms, cnt, C.byref(fl))
+        fls = (C.c_double * N.NCLASS)()
+        lib.wd_prof_collect_flops(pms, cnt, fls)
         lib.wd_prof_enable(0)
-        out["kernel_classes"] = {N.CLASS_NAMES[i]: dict(ms_per_step=pms[i], launches_per_step=int(cnt[i])) for i in range(N.NCLASS)}
-        out["gemm_tflops_algorithmic"] = fl.value / (pms[0] * 1e-3) / 1e12 if pms[0] > 0 else None
+        kc = {}
+        for i in range(N.NCLASS):
+            d = dict(ms_per_step=pms[i], launches_per_step=int(cnt[i]))
+            if i in CONTRACTION_CLASSES and pms[i] > 0 and fls[i] > 0:
+                tf = fls[i] / (pms[i] * 1e-3) / 1e12
+                d.update(gflop_per_step=fls[i] / 1e9, tflops=tf, mfma_frac=tf / PEAK_BF16_TFLOPS)
+            kc[N.CLASS_NAMES[i]] = d
+        out["kernel_classes"] = kc
+        out["gemm_tflops_algorithmic"] = fls[0] / (pms[0] * 1e-3) / 1e12 if pms[0] > 0 else None
+        # roofline of the training step's contractions (eager pass, hipEvent pair per launch; algorithmic FLOPs, each multiply-add
+        # once - the split-bf16 path issues three MFMAs per product)
+        tot_fl = sum(fls[i] for i in CONTRACTION_CLASSES)
+        tot_ms = sum(pms[i] for i in CONTRACTION_CLASSES)
+        if tot_ms > 0:
+            dwc = kc.get("weight_gradient", {})
+            out["roofline"] = dict(bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_TFLOPS, achieved=tot_fl / (tot_ms * 1e-3) / 1e12,
+                                   frac=tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, mfma_issue_factor=3,
+                                   gflop_per_step=tot_fl / 1e9, contraction_ms_per_step=tot_ms,
+                                   weight_gradient_tflops=dwc.get("tflops"),
+                                   note="all contraction classes of one training step (forward, data gradients, weight gradients); "
+                                        "profiles/rNN_pmc_mfma_util_train.json holds the MFMA-busy counters per kernel")
     return out
 
 
@@ -440,6 +459,7 @@ CONTRACTION_CLASSES = {
     9: "wd_gemmw_kernel<3,1> (64x320 tiles, A rows through LDS, fragment-major weights straight into the MFMA operand registers: "
        "the 3x3 convolutions and 1x1 projections of the 8x32 level)",
     10: "wd_ff_kernel<3> (GEGLU feed-forward + residual per 64-token panel, hidden activations on chip)",
+    11: "wd_dw_kernel<3> (weight gradients of the training step from the row-major planes, transposed LDS reads)",
 }
 PMC_KEYS = {0: "wd_gemm2_kernel<128, 160, 3, 2, false, true>", 9: "wd_gemmw_kernel<3, 1, false>", 10: "wd_ff_kernel<3, true>"}
 

@@ -293,7 +293,8 @@ def test_gemm_weights_to_registers_kernel(B, hh, ww, c1, c2, n, ksplit, npass, t
 
 @pytest.mark.parametrize("B,hh,ww,cin,c2,n,taps,silu,eps,ksplit", [(3, 8, 32, 64, 0, 320, 9, 1, 1e-5, 1), (2, 8, 32, 320, 0, 320, 1, 0, 1e-6, 1),
                                                                   (2, 8, 32, 128, 64, 320, 9, 1, 1e-5, 1), (5, 4, 16, 320, 0, 320, 9, 1, 1e-5, 2),
-                                                                  (64, 8, 32, 64, 0, 320, 9, 1, 1e-5, 1)])
+                                                                  (64, 8, 32, 64, 0, 320, 9, 1, 1e-5, 1), (2, 8, 32, 320, 0, 320, 9, 1, 1e-5, 1),
+                                                                  (3, 4, 16, 128, 0, 320, 9, 0, 1e-6, 1)])
 def test_gemm_groupnorm_of_the_input_while_staging(B, hh, ww, cin, c2, n, taps, silu, eps, ksplit):
     """wd_gemm_args.a32*: src[0] is the fp32 map and the consumer's GroupNorm (+ SiLU) is applied while the weights-to-registers
     kernel stages its rows - vs F.group_norm -> SiLU -> conv in fp64 (zero padding applies to the NORMALISED map), and vs the

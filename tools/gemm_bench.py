@@ -52,6 +52,8 @@ def main():
                     "the result is compared with the default kernel's first")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
                     "2: same, then read the weights once (emulates a prefetch) before the launch")
+    ap.add_argument("--a32", type=int, default=0, help="1 (with --wdirect 2): src[0] is the fp32 map, GroupNorm + SiLU applied inside "
+                    "the GEMM (wd_gemm_args.a32*; 3x3 single-source shapes take the slab kernel wd_gemms_kernel)")
     ap.add_argument("--mnk", default="", help="m,n,k of a plain product (no taps) instead of --shape, e.g. 320,320,16384: the "
                     "weight-gradient GEMMs of the training step (reduction over the tokens)")
     a = ap.parse_args()
@@ -110,6 +112,15 @@ def main():
             N.check(lib.wd_gemm_pack_w(wt[0].data_ptr(), wt[1].data_ptr(), cout, ktot, wf[0].data_ptr(), wf[1].data_ptr(), st), "pack_w")
             g.w_hi, g.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
             g.w_layout, g.slab_rows, g.tile = 3, (w if ntaps == 9 else 0), (64320 if a.wdirect == 2 else 128160)
+            if a.a32:
+                x32 = torch.randn(m, cin, device=DEV)
+                nchunk = lib.wd_gn_nchunk(hw)
+                part = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+                N.check(lib.wd_gn_stats(x32.data_ptr(), cin, B, hw, cin, cin // 32, part.data_ptr(), st), "stats")
+                gam, bet = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+                g.a32, g.a32_ld, g.a32_part, g.a32_nchunk, g.a32_pcpg, g.a32_cpg = x32.data_ptr(), cin, part.data_ptr(), nchunk, cin // 32, cin // 32
+                g.a32_gamma, g.a32_beta, g.a32_eps, g.a32_silu = gam.data_ptr(), bet.data_ptr(), 1e-5, 1
+                keep_a32 = (x32, part, gam, bet)
             if a.ksplit != 1:
                 g.ksplit = a.ksplit
             out.zero_()
