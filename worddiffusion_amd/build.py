@@ -17,6 +17,11 @@ LIB = os.path.join(HERE, "libwdiff_hip.so")
 SOURCES = ["wd_gemm.hip", "wd_gemmw.hip", "wd_ff.hip", "wd_dw.hip", "wd_norm.hip", "wd_attn.hip", "wd_xattn.hip", "wd_misc.hip", "wd_train.hip", "wd_bwd.hip", "wd_pack.hip", "wd_runtime.hip"]
 HEADERS = [os.path.join(CSRC, "wd_common.h"), os.path.join(CSRC, "wd_gemm_epi.h"), os.path.join(CSRC, "wd_gemm_priv.h"), os.path.join(os.path.dirname(HERE), "include", "wdiff_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+# per-file flags.  wd_attn.hip: MFMA accumulators in ordinary VGPRs - for its 256-thread kernels hipcc otherwise keeps them in AGPRs and
+# moves every value the softmax touches through v_accvgpr_read / _write (432 such moves per key block in attn_mfma_kernel<5,3>);
+# the 4x16-level attention launches run 7-8 % faster without them, the 8x32 ones 2-3 %.  (The 512-thread GEMM kernels are tuned
+# against the default register allocation and keep it.)
+FILE_FLAGS = {"wd_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 if os.environ.get("WDIFF_EXPERIMENTAL", "0") != "0":  # the opt-in GEMM variants that lost their A/B (csrc/wd_gemm.hip)
     FLAGS.append("-DWDIFF_EXPERIMENTAL")
 if os.environ.get("WDIFF_STAMPS", "0") != "0":  # s_memtime stamps inside wd_dw_kernel / wd_gemmw_kernel (tools/*_bench.py --stamps)
@@ -35,7 +40,7 @@ def _digest(paths) -> str:
     for p in paths:
         with open(p, "rb") as f:
             h.update(hashlib.sha256(f.read()).digest())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + FILE_FLAGS.get(os.path.basename(paths[0]), [])).encode())
     return h.hexdigest()
 
 
@@ -64,7 +69,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
