@@ -494,6 +494,11 @@ int wd_attention_bwd_small(const float* q, int ldq, const float* k, int ldk, con
 int wd_dout_prep_rows(void);
 int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int mpad, wd_bf16* pl_hi, wd_bf16* pl_lo, wd_bf16* t_hi,
                  wd_bf16* t_lo, float* colpart, void* stream);
+/* The same outputs for d(output) of the GEGLU projection (unet.py:125-136 under autograd) WITHOUT materialising it: computed on the
+ * fly from the saved pre-activation u = [x | gate] ([m][u_ld]) and the gradient dh [m][dh_ld] of x . gelu(gate); n = npad = 2 inner,
+ * inner % 64 == 0.  Replaces wd_geglu_bwd + wd_dout_prep. */
+int wd_dout_prep_geglu(const float* u, int u_ld, const float* dh, int dh_ld, int m, int inner, int mpad, wd_bf16* pl_hi, wd_bf16* pl_lo,
+                       wd_bf16* t_hi, wd_bf16* t_lo, float* colpart, void* stream);
 int wd_colsum_finish(const float* part, int nblk, int c, int nseg, float* out, int out_ld, int accumulate, float scale,
                      void* stream);
 /* The same finish for `n` (partials -> gradient) pairs in one launch (nseg = 1 each).  `table` is a device array of

@@ -193,6 +193,42 @@ def test_weight_gradient_kernel_rejects_bad_arguments():
     assert lib.wd_dw(C.byref(a), _st()) == N.WD_EINVAL
 
 
+@pytest.mark.parametrize("m,inner,extra", [(512, 128, 0), (4096, 1280, 0), (200, 64, 8)])
+def test_geglu_backward_inside_the_dout_preparation(m, inner, extra):
+    """wd_dout_prep_geglu = wd_geglu_bwd followed by wd_dout_prep, without the fp32 intermediate: same planes, transposed planes and
+    64-row column sums."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(m + inner)
+    u = torch.randn(m, 2 * inner + extra, generator=g).to(DEV)
+    dh = torch.randn(m, inner + extra, generator=g).to(DEV)
+    n, mpad = 2 * inner, (m + 63) // 64 * 64
+    du = torch.empty(m, n, device=DEV)
+    N.check(lib.wd_geglu_bwd(u.data_ptr(), u.shape[1], dh.data_ptr(), dh.shape[1], m, inner, du.data_ptr(), n, _st()), "geglu_bwd")
+    outs = []
+    for fused in (0, 1):
+        pl = torch.full((2, m, n), -1, dtype=torch.bfloat16, device=DEV)
+        tp = torch.zeros((2, n, mpad), dtype=torch.bfloat16, device=DEV)
+        cp = torch.full((mpad // 64, n), float("nan"), device=DEV)
+        if fused:
+            N.check(lib.wd_dout_prep_geglu(u.data_ptr(), u.shape[1], dh.data_ptr(), dh.shape[1], m, inner, mpad, pl[0].data_ptr(),
+                                           pl[1].data_ptr(), tp[0].data_ptr(), tp[1].data_ptr(), cp.data_ptr(), _st()), "prep geglu")
+        else:
+            N.check(lib.wd_dout_prep(du.data_ptr(), n, m, n, n, mpad, pl[0].data_ptr(), pl[1].data_ptr(), tp[0].data_ptr(),
+                                     tp[1].data_ptr(), cp.data_ptr(), _st()), "prep")
+        torch.cuda.synchronize()
+        outs.append((pl.clone(), tp.clone(), cp.clone()))
+    # (not bit for bit: the two kernels contract their multiplications differently - a last-place difference in fp32)
+    (pl0, tp0, cp0), (pl1, tp1, cp1) = outs
+    assert max_rel(unplanes(pl1).cpu(), unplanes(pl0).cpu()) < 1e-5
+    assert max_rel(unplanes(tp1).cpu(), unplanes(tp0).cpu()) < 1e-5
+    assert torch.equal(unplanes(tp1)[:, :m].t(), unplanes(pl1))
+    assert max_rel(cp1.cpu(), cp0.cpu()) < 1e-5
+    # and against autograd
+    uu = u[:, :n].double().cpu().requires_grad_(True)
+    (uu[:, :inner] * F.gelu(uu[:, inner:])).backward(dh[:, :inner].double().cpu())
+    assert max_rel(unplanes(outs[1][0]).cpu(), uu.grad) < 1e-5
+
+
 def test_transpose_planes_and_colsum():
     lib = N.lib()
     g = torch.Generator().manual_seed(1)

@@ -123,6 +123,7 @@ _SIGS = {
     "wd_xattn_fused": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "wd_dout_prep_rows": (_i, []),
     "wd_dout_prep": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wd_dout_prep_geglu": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wd_colsum_finish": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _f, _vp]),
     "wd_colsum_entry_bytes": (_i, []),
     "wd_colsum_finish_multi": (_i, [_vp, _i, _i, _vp]),

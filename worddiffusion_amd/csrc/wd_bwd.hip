@@ -102,10 +102,14 @@ __global__ void __launch_bounds__(256) transpose_planes_kernel(const void* __res
 // ---- one pass over d(output) [M][n] fp32 for everything its layer's backward needs: row-major split planes (operand of the
 // data-gradient GEMM), transposed split planes (operand of the weight-gradient GEMM) and per-64-row column sums (bias /
 // FiLM gradients after wd_colsum_finish).  Any of the three outputs may be NULL.
+// GEGLU: d is not read but computed - d(output) of the GEGLU projection from the saved pre-activation u = [x | gate] ([m][ld], ld >=
+// 2 inner) and the gradient dh [m][dh_ld] of a . gelu(gate): columns [0, inner) = dh gelu(gate), [inner, 2 inner) = dh x gelu'(gate)
+// (wd_geglu_bwd's arithmetic) - so the 2 inner wide fp32 gradient is never written and read back (168 + 168 MB per 8x32 block).
+template <bool GEGLU>
 __global__ void __launch_bounds__(256) dout_prep_kernel(const float* __restrict__ d, int ld, int m, int n, int npad, int mpad,
                                                         wd_bf16* __restrict__ pl_hi, wd_bf16* __restrict__ pl_lo,
                                                         wd_bf16* __restrict__ t_hi, wd_bf16* __restrict__ t_lo,
-                                                        float* __restrict__ colpart) {
+                                                        float* __restrict__ colpart, const float* __restrict__ dh, int dh_ld, int inner) {
     __shared__ wd_bf16 th[64][68], tl[64][68];
     __shared__ float cs[16][65];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -117,7 +121,20 @@ __global__ void __launch_bounds__(256) dout_prep_kernel(const float* __restrict_
         const int r = r4 + 16 * ps;
         const int mm = m0 + r, cc = c0 + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mm < m && cc < n) {
+        if (GEGLU) {
+            if (mm < m && cc < n) {  // (n = 2 inner, inner % 64 == 0: a 64-column block lies in one half)
+                const int j = cc < inner ? cc : cc - inner;
+                const float4 g = *reinterpret_cast<const float4*>(d + (long)mm * ld + inner + j);
+                const float4 dd = *reinterpret_cast<const float4*>(dh + (long)mm * dh_ld + j);
+                if (cc < inner) {
+                    v = make_float4(dd.x * wd_gelu_erf(g.x), dd.y * wd_gelu_erf(g.y), dd.z * wd_gelu_erf(g.z), dd.w * wd_gelu_erf(g.w));
+                } else {
+                    const float4 xa = *reinterpret_cast<const float4*>(d + (long)mm * ld + j);
+                    v = make_float4(dd.x * xa.x * gelu_grad(g.x), dd.y * xa.y * gelu_grad(g.y), dd.z * xa.z * gelu_grad(g.z),
+                                    dd.w * xa.w * gelu_grad(g.w));
+                }
+            }
+        } else if (mm < m && cc < n) {
             const float* xp = d + (long)mm * ld + cc;
             if (cc + 3 < n) v = *reinterpret_cast<const float4*>(xp);
             else v = make_float4(xp[0], cc + 1 < n ? xp[1] : 0.f, cc + 2 < n ? xp[2] : 0.f, 0.f);
@@ -1405,8 +1422,22 @@ extern "C" int wd_dout_prep(const float* d, int ld, int m, int n, int npad, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_OTHER, st);
     const int ncols = pl_hi ? npad : n;
-    hipLaunchKernelGGL(dout_prep_kernel, dim3((mpad + 63) / 64, (ncols + 63) / 64), dim3(256), 0, st, d, ld, m, n, npad, mpad,
-                       pl_hi, pl_lo, t_hi, t_lo, colpart);
+    hipLaunchKernelGGL(dout_prep_kernel<false>, dim3((mpad + 63) / 64, (ncols + 63) / 64), dim3(256), 0, st, d, ld, m, n, npad, mpad,
+                       pl_hi, pl_lo, t_hi, t_lo, colpart, nullptr, 0, 0);
+    return wd_check_launch();
+}
+
+extern "C" int wd_dout_prep_geglu(const float* u, int u_ld, const float* dh, int dh_ld, int m, int inner, int mpad, wd_bf16* pl_hi,
+                                  wd_bf16* pl_lo, wd_bf16* t_hi, wd_bf16* t_lo, float* colpart, void* stream) {
+    if (!u || !dh || m <= 0 || inner <= 0 || inner % 64 || mpad < m || (mpad & 3) || u_ld < 2 * inner || (u_ld & 3) || dh_ld < inner ||
+        (dh_ld & 3))
+        return WD_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dh)) & 15) || (!pl_hi && !t_hi && !colpart)) return WD_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WdLaunchScope scope(WD_CLS_OTHER, st);
+    const int n = 2 * inner;
+    hipLaunchKernelGGL(dout_prep_kernel<true>, dim3((mpad + 63) / 64, n / 64), dim3(256), 0, st, u, u_ld, m, n, n, mpad, pl_hi, pl_lo,
+                       t_hi, t_lo, colpart, dh, dh_ld, inner);
     return wd_check_launch();
 }
 

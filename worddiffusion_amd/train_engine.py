@@ -64,6 +64,7 @@ class TrainEngine(UNetEngine):
         self.fuse_ff = self.fuse_proj = False
         self.fuse_gn_in = 0
         self.use_dw = os.environ.get("WDIFF_TRAIN_DW", "1") != "0"  # weight gradients through wd_dw (csrc/wd_dw.hip) where it applies
+        self.fuse_geglu_bwd = os.environ.get("WDIFF_FUSE_GEGLU_BWD", "1") != "0"  # GEGLU backward inside the d(out) preparation of ff1
         self.fuse_gn_bwd = os.environ.get("WDIFF_FUSE_GN_BWD", "1") != "0"  # GroupNorm backward in one pass (wd_gn_bwd_fused)
         self.dw_group_max = int(os.environ.get("WDIFF_DW_GROUP", "8"))  # single-tap layers of one shape per grouped launch (1: off)
         self._dw_pending: Dict[tuple, list] = {}
@@ -329,7 +330,7 @@ class TrainEngine(UNetEngine):
                 P.bwd.append((self.lib.wd_dw_group, (C.byref(a), C.cast(arr, C.c_void_p), dev.data_ptr(), len(grp)),
                               "dW group: " + ", ".join(it["what"] for it in grp)))
 
-    def _bwd_linear(self, P, what, dout: torch.Tensor, M, n, hw_out, segs, bias=(), film_off=None, npad=None):
+    def _bwd_linear(self, P, what, dout: torch.Tensor, M, n, hw_out, segs, bias=(), film_off=None, npad=None, geglu=None):
         """Backward of out[M, n] = sum_seg gather(planes_seg) . W_seg^T + bias (+ FiLM row vector).
 
         seg keys: planes [2, rows, ld], c, ntaps, ftab (forward table or None), hw_src (forward source positions per
@@ -339,7 +340,9 @@ class TrainEngine(UNetEngine):
         ops = P.bwd
         lib = self.lib
         npad = n if npad is None else npad
-        ldd = dout.shape[1]
+        # geglu = (u, dh, inner): d(output) is the GEGLU projection's and is NOT materialised - wd_dout_prep_geglu derives its planes
+        # and column sums from the saved pre-activation and the gradient of the activation's output (dout is None then)
+        ldd = dout.shape[1] if dout is not None else n
         mpad = _rup(M, 64)
         lo_ok = self.npass == 3
         need_dx = any(s.get("dx") for s in segs)
@@ -377,7 +380,15 @@ class TrainEngine(UNetEngine):
             else:
                 colpart = self._scratch("colpart", self._max_colpart, torch.float32)
             assert (mpad // 64) * n <= colpart.numel(), what
-        if need_dpl or need_dw or fuse_cs:
+        if geglu is not None:
+            u, dh, inner = geglu
+            assert dout is None and n == 2 * inner and npad == n and fuse_cs and film_off is None, what
+            ops.append((lib.wd_dout_prep_geglu, (u.data_ptr(), u.shape[1], dh.data_ptr(), dh.shape[1], M, inner, mpad,
+                                                 _ptr(dpl[0]) if need_dpl else None,
+                                                 (_ptr(dpl[1]) if lo_ok else None) if need_dpl else None,
+                                                 _ptr(doutT[0]) if need_dw else None, _ptr(doutT[1]) if need_dw else None,
+                                                 _ptr(colpart)), what + ":prep(geglu bwd)"))
+        elif need_dpl or need_dw or fuse_cs:
             # one pass over d(output): row-major planes (data gradient, wd_dw), transposed planes (wd_gemm weight gradient), column sums
             ops.append((lib.wd_dout_prep, (dout.data_ptr(), ldd, M, n, npad, mpad, _ptr(dpl[0]) if need_dpl else None,
                                            (_ptr(dpl[1]) if lo_ok else None) if need_dpl else None,
@@ -736,14 +747,18 @@ class TrainEngine(UNetEngine):
                                  [dict(planes=rec["ffh"], c=ffi, ntaps=1, hw_src=hw, wb="B:" + p + ".ff2.w",
                                        wgrad=self._pgrad(tb.ff.net[2].weight), dx=[(dffh, ffi, 0, 0, ffi)], dx_rows=M,
                                        dx_hw=hw)], bias=[self._pgrad(tb.ff.net[2].bias)])
-                du = self._f32(P, M, 2 * ffi)
-                bops.append((lib.wd_geglu_bwd, (rec["u"].data_ptr(), 2 * ffi, dffh.data_ptr(), ffi, M, ffi, du.data_ptr(), 2 * ffi),
-                             p + ".geglu:bwd"))
                 dn3 = self._f32(P, M, inner)
-                self._bwd_linear(P, p + ".ff1", du, M, 2 * ffi, hw,
-                                 [dict(planes=rec["n3"], c=inner, ntaps=1, hw_src=hw, wb="B:" + p + ".ff1.w",
-                                       wgrad=self._pgrad(tb.ff.net[0].proj.weight), dx=[(dn3, inner, 0, 0, inner)], dx_rows=M,
-                                       dx_hw=hw)], bias=[self._pgrad(tb.ff.net[0].proj.bias)])
+                ff1_seg = [dict(planes=rec["n3"], c=inner, ntaps=1, hw_src=hw, wb="B:" + p + ".ff1.w",
+                                wgrad=self._pgrad(tb.ff.net[0].proj.weight), dx=[(dn3, inner, 0, 0, inner)], dx_rows=M, dx_hw=hw)]
+                if self.fuse_geglu_bwd and ffi % 64 == 0:
+                    # d(GEGLU pre-activation) goes straight to operand planes + bias column sums (never written as fp32)
+                    self._bwd_linear(P, p + ".ff1", None, M, 2 * ffi, hw, ff1_seg, bias=[self._pgrad(tb.ff.net[0].proj.bias)],
+                                     geglu=(rec["u"], dffh, ffi))
+                else:
+                    du = self._f32(P, M, 2 * ffi)
+                    bops.append((lib.wd_geglu_bwd, (rec["u"].data_ptr(), 2 * ffi, dffh.data_ptr(), ffi, M, ffi, du.data_ptr(), 2 * ffi),
+                                 p + ".geglu:bwd"))
+                    self._bwd_linear(P, p + ".ff1", du, M, 2 * ffi, hw, ff1_seg, bias=[self._pgrad(tb.ff.net[0].proj.bias)])
                 self._ln_bwd(P, p + ".norm3:bwd", rec["x3"], M, inner, tb.norm3, p + ".norm3", dn3, dcur, 1)
                 # ---- the two cross-attentions, last first
                 for tag in ("a2", "a1"):
