@@ -307,12 +307,13 @@ class TrainEngine(UNetEngine):
     def _flush_dw(self, P):
         """Emits the weight-gradient launches put off by _bwd_linear: layers of one shape as ONE grouped wd_dw_group launch."""
         pend, self._dw_pending = self._dw_pending, {}
-        for (M, n, c, hw), items in pend.items():
+        for (M, n, c, hw, ntaps, hw_src, _), items in pend.items():
+            ftab = items[0]["ftab"]
             for lo in range(0, len(items), self.dw_group_max):
                 grp = items[lo:lo + self.dw_group_max]
                 if len(grp) == 1:
                     it = grp[0]
-                    self._dw(P.bwd, it["what"], it["dpl"], it["d_ld"], it["planes"], it["col_off"], c, None, 1, hw, hw, M, n,
+                    self._dw(P.bwd, it["what"], it["dpl"], it["d_ld"], it["planes"], it["col_off"], c, ftab, ntaps, hw, hw_src, M, n,
                              it["wg"], it["out_ld"], self._pacc(it["wg"]))
                     continue
                 arr = (N.WdDwItem * len(grp))()
@@ -325,7 +326,8 @@ class TrainEngine(UNetEngine):
                 dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
                 a = N.WdDwArgs()
                 a.ws, a.ws_floats = self._ws.data_ptr(), self._ws.numel()
-                a.ntaps, a.hw_out, a.hw_src, a.m, a.n, a.c, a.npass, a.nslice = 1, hw, hw, M, n, c, self.npass, 0
+                a.gather = _ptr(ftab)
+                a.ntaps, a.hw_out, a.hw_src, a.m, a.n, a.c, a.npass, a.nslice = ntaps, hw, hw_src, M, n, c, self.npass, 0
                 P.keep += [arr, dev, a]
                 P.bwd.append((self.lib.wd_dw_group, (C.byref(a), C.cast(arr, C.c_void_p), dev.data_ptr(), len(grp)),
                               "dW group: " + ", ".join(it["what"] for it in grp)))
@@ -358,9 +360,13 @@ class TrainEngine(UNetEngine):
         need_dpl = need_dx or any(s["_dw"] for s in segs)
         # single-tap layers wait for the others of their shape (one grouped launch at the end of the block's backward, _flush_dw):
         # their d(out) planes then need a buffer of their own
+        # (3x3 layers join a group only where a launch of their own would run short token slices - the 4 x 16 level: < 16 units of 64
+        # tokens per slice -; the two convolutions of a ResBlock there share a launch)
         for s in segs:
-            s["_defer"] = bool(s["_dw"] and self.dw_group_max > 1 and s["ntaps"] == 1 and s.get("ftab") is None and
-                               self.lib.wd_dw_group_slices(M, n, s["c"], 1, 2) * 2 * n * s["c"] <= self._ws.numel())
+            taps = s["ntaps"]
+            short = taps == 1 or (M // 64) // max(1, self.lib.wd_dw_slices(M, n, s["c"], taps)) < 16
+            s["_defer"] = bool(s["_dw"] and self.dw_group_max > 1 and short and (taps == 1) == (s.get("ftab") is None) and
+                               self.lib.wd_dw_group_slices(M, n, s["c"], taps, 2) * 2 * n * s["c"] * taps <= self._ws.numel())
         dpl = doutT = colpart = None
         if need_dpl and any(s["_defer"] for s in segs):
             dpl = torch.empty(2, M, npad, dtype=torch.bfloat16, device=self.device)
@@ -408,8 +414,11 @@ class TrainEngine(UNetEngine):
             k = ntaps * c
             ftab = s.get("ftab")
             if s["_defer"]:
-                self._dw_pending.setdefault((M, n, c, hw_dw), []).append(
-                    dict(what=f"{what}:dW{si}", dpl=dpl, d_ld=npad, planes=planes, col_off=s.get("col_off", 0), wg=wg, out_ld=k))
+                key = (M, n, c, hw_out if ftab is not None else hw_dw, ntaps, s["hw_src"] if ftab is not None else hw_dw,
+                       ftab.data_ptr() if ftab is not None else 0)
+                self._dw_pending.setdefault(key, []).append(
+                    dict(what=f"{what}:dW{si}", dpl=dpl, d_ld=npad, planes=planes, col_off=s.get("col_off", 0), wg=wg, out_ld=k,
+                         ftab=ftab))
                 continue
             if s["_dw"]:
                 self._dw(ops, f"{what}:dW{si}", dpl, npad, planes, s.get("col_off", 0), c, ftab, ntaps,
