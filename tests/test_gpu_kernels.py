@@ -1019,6 +1019,99 @@ def test_gn_silu_conv3x3_few_output_channels(B, h, w, c, oc, silu):
     assert not lib.wd_gn_conv3x3_few_supported(c, 65, oc) and not lib.wd_gn_conv3x3_few_supported(c, w, 5)
 
 
+@pytest.mark.parametrize("B,cin,cout,cpg,silu,film,resid,w", [(64, 320, 320, 10, 1, True, False, 16), (5, 64, 320, 20, 0, False, True, 16),
+                                                               (16, 640, 320, 10, 1, True, False, 16), (3, 128, 160, 40, 1, False, False, 32),
+                                                               (7, 384, 480, 10, 0, False, True, 16)])
+def test_gemm_small_maps_whole_k_in_the_workgroup(B, cin, cout, cpg, silu, film, resid, w):
+    """wd_gemm_args.tile = 64080 (wd_gemmq_kernel): 3x3 convolution over 64-position samples, 64 x 80 tiles, the input rows kept in
+    LDS, the eight waves splitting K - plain epilogue (bias / FiLM / residual / statistics / planes of the result) and with the
+    consumer's GroupNorm (+SiLU) in the same launch, vs fp64 torch and vs the default kernel."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B + cin + cout + w)
+    h = 64 // w
+    hw, m = h * w, B * h * w
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fl = torch.randn(B, cout, generator=g) * 0.3 if film else None
+    rs = torch.randn(m, cout, generator=g) if resid else None
+    gam, bet = torch.randn(cout, generator=g) * 0.2 + 1, torch.randn(cout, generator=g) * 0.2
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    if film:
+        ref = ref + fl.double()[:, :, None, None]
+    if resid:
+        ref = ref + rs.double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    refn = F.group_norm(ref, cout // cpg, gam.double(), bet.double(), 1e-5)
+    if silu:
+        refn = F.silu(refn)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(m, -1)  # noqa: E731
+    tab, _, _ = conv_gather_table(h, w, "same")
+    pl = planes_of(tok(x).contiguous().to(DEV))
+    wp = planes_of(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(DEV))
+    wf = torch.empty_like(wp)
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), cout, 9 * cin, wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    tabd = torch.from_numpy(tab).to(DEV)
+    pc = 10 if cpg % 10 == 0 else cpg
+
+    def args_for(gn: bool, small: bool):
+        a = N.WdGemmArgs()
+        s = N.WdSrc()
+        s.hi, s.lo, s.gather = pl[0].data_ptr(), pl[1].data_ptr(), tabd.data_ptr()
+        s.ld, s.c, s.ntaps, s.hw_src = cin, cin, 9, hw
+        a.src[0] = s
+        a.nsrc, a.npass = 1, 3
+        if small:
+            a.w_hi, a.w_lo, a.w_layout, a.tile, a.slab_rows = wf[0].data_ptr(), wf[1].data_ptr(), 3, 64080, w
+        else:
+            a.w_hi, a.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
+        a.m, a.n, a.ktot, a.hw_out = m, cout, 9 * cin, hw
+        keep = dict(bias=bias.to(DEV), out=torch.full((m, cout), float("nan"), device=DEV),
+                    opl=torch.zeros(2, m, cout, dtype=torch.bfloat16, device=DEV), ws=torch.empty(8 * m * cout, device=DEV),
+                    part=torch.zeros(B, 1, cout // pc, 2, dtype=torch.float64, device=DEV), gam=gam.to(DEV), bet=bet.to(DEV))
+        a.bias = keep["bias"].data_ptr()
+        if film:
+            keep["fl"] = fl.to(DEV)
+            a.rowvec, a.rowvec_ld = keep["fl"].data_ptr(), cout
+        if resid:
+            keep["rs"] = rs.to(DEV)
+            a.resid, a.resid_ld = keep["rs"].data_ptr(), cout
+        a.out_f32, a.out_ld = keep["out"].data_ptr(), cout
+        a.out_hi, a.out_lo, a.out_pl_ld = keep["opl"][0].data_ptr(), keep["opl"][1].data_ptr(), cout
+        a.ws, a.ws_floats = keep["ws"].data_ptr(), keep["ws"].numel()
+        a.stat_part, a.stat_cpg = keep["part"].data_ptr(), pc
+        if gn:
+            a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_silu, a.gn_cpg = keep["gam"].data_ptr(), keep["bet"].data_ptr(), 1e-5, silu, cpg
+        return a, keep
+
+    # plain epilogue: result, planes of the result, statistics - against fp64 and against the default kernel
+    a, k = args_for(False, True)
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm 64080")
+    torch.cuda.synchronize()
+    assert max_rel(k["out"].cpu(), tok(ref)) < 2e-5
+    assert max_rel(unplanes(k["opl"]).cpu(), tok(ref)) < 2e-5
+    a0, k0 = args_for(False, False)
+    N.check(lib.wd_gemm(C.byref(a0), _st()), "wd_gemm")
+    torch.cuda.synchronize()
+    assert max_rel(k["out"].cpu(), k0["out"].cpu()) < 5e-6
+    assert torch.allclose(k["part"], k0["part"], rtol=2e-4, atol=2e-3)  # (fp32 partial sums in a different order)
+    # replay: bit-identical (fixed summation order over the eight waves)
+    a2, k2 = args_for(False, True)
+    N.check(lib.wd_gemm(C.byref(a2), _st()), "wd_gemm 64080 again")
+    torch.cuda.synchronize()
+    assert torch.equal(k["out"], k2["out"])
+    # the consumer's GroupNorm in the same launch (160-multiple widths only, as the combine-launch form)
+    ag, kg = args_for(True, True)
+    rc = lib.wd_gemm(C.byref(ag), _st())
+    if cout % 160:
+        assert rc != 0
+        return
+    N.check(rc, "wd_gemm 64080 + GroupNorm")
+    torch.cuda.synchronize()
+    assert torch.equal(kg["out"], k["out"])
+    assert max_rel(unplanes(kg["opl"]).cpu(), tok(refn)) < 3e-5
+    assert torch.allclose(kg["part"], k["part"], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("B,cin,cout,cpg,silu,film,resid", [(64, 320, 320, 10, 1, True, False), (5, 64, 320, 20, 0, False, True),
                                                              (16, 128, 160, 40, 1, False, False)])
 def test_gemm_groupnorm_in_the_combine_launch(B, cin, cout, cpg, silu, film, resid):

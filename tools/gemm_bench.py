@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="batch size (default: the module's B)")
     ap.add_argument("--conv3", type=int, default=0, help="1: row-shared-taps kernel for the 3x3 shapes (w_layout 2)")
     ap.add_argument("--stamps", type=int, default=0, help="1: per-stage cycle stamps of workgroup 0 (s_memtime)")
-    ap.add_argument("--wdirect", type=int, default=0, help="1: fragment-major weights, 64 x 320 weights-to-registers kernel (w_layout 3); "
+    ap.add_argument("--wdirect", type=int, default=0, help="1 / 2: fragment-major weights, 128 x 160 / 64 x 320 weights-to-registers kernel (w_layout 3); 3: the 64 x 80 whole-K kernel for 64-position samples (tile 64080); "
                     "the result is compared with the default kernel's first")
     ap.add_argument("--cold", type=int, default=0, help="1: flush caches (1 GiB write) before every launch; "
                     "2: same, then read the weights once (emulates a prefetch) before the launch")
@@ -111,7 +111,7 @@ def main():
             wf = torch.empty_like(wt)
             N.check(lib.wd_gemm_pack_w(wt[0].data_ptr(), wt[1].data_ptr(), cout, ktot, wf[0].data_ptr(), wf[1].data_ptr(), st), "pack_w")
             g.w_hi, g.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
-            g.w_layout, g.slab_rows, g.tile = 3, (w if ntaps == 9 else 0), (64320 if a.wdirect == 2 else 128160)
+            g.w_layout, g.slab_rows, g.tile = 3, (w if ntaps == 9 else 0), (64320 if a.wdirect == 2 else 64080 if a.wdirect == 3 else 128160)
             if a.a32:
                 x32 = torch.randn(m, cin, device=DEV)
                 nchunk = lib.wd_gn_nchunk(hw)
@@ -127,7 +127,18 @@ def main():
             N.check(lib.wd_gemm(C.byref(g), st), name + " (w-direct)")
             torch.cuda.synchronize()
             print(f"{name}: w-direct vs default kernel max |diff| {float((out - ref).abs().max()):.3e}  (max |ref| {float(ref.abs().max()):.3f})", flush=True)
-        if a.stamps:
+        if a.stamps and a.wdirect == 3:
+            sb = torch.zeros(64, dtype=torch.int64, device=DEV)
+            g.ws, g.ws_floats, g.dbg = sb.data_ptr(), 0, a.dbg | 0x100
+            N.check(lib.wd_gemm(C.byref(g), st), name)
+            torch.cuda.synchronize()
+            v = sb.cpu().view(8, 8)
+            for wv in range(8):
+                t = v[wv]
+                print(f"   wave {wv}: fill+barrier {int(t[1] - t[0])}  loop {int(t[4] - t[1])}  wait-for-others {int(t[5] - t[4])}  "
+                      f"reduce {int(t[6] - t[5])}  epilogue {int(t[7] - t[6])}   total {int(t[7] - t[0])} cycles")
+            g.dbg, g.ws, g.ws_floats = a.dbg, None, 0
+        elif a.stamps:
             nk = (ktot // 64 + 1) & ~1 if a.wdirect else ktot // 64
             sb = torch.zeros(8 * nk * 4, dtype=torch.int64, device=DEV)
             g.ws, g.ws_floats, g.dbg = sb.data_ptr(), 0, a.dbg | 0x100

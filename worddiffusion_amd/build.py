@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwdiff_hip.so")
-SOURCES = ["wd_gemm.hip", "wd_gemmw.hip", "wd_ff.hip", "wd_dw.hip", "wd_norm.hip", "wd_attn.hip", "wd_xattn.hip", "wd_misc.hip", "wd_train.hip", "wd_bwd.hip", "wd_pack.hip", "wd_runtime.hip"]
+SOURCES = ["wd_gemm.hip", "wd_gemmw.hip", "wd_gemmq.hip", "wd_ff.hip", "wd_dw.hip", "wd_norm.hip", "wd_attn.hip", "wd_xattn.hip", "wd_misc.hip", "wd_train.hip", "wd_bwd.hip", "wd_pack.hip", "wd_runtime.hip"]
 HEADERS = [os.path.join(CSRC, "wd_common.h"), os.path.join(CSRC, "wd_gemm_epi.h"), os.path.join(CSRC, "wd_gemm_priv.h"), os.path.join(os.path.dirname(HERE), "include", "wdiff_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 # per-file flags.  wd_attn.hip: MFMA accumulators in ordinary VGPRs - for its 256-thread kernels hipcc otherwise keeps them in AGPRs and
@@ -25,7 +25,7 @@ FILE_FLAGS = {"wd_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 if os.environ.get("WDIFF_EXPERIMENTAL", "0") != "0":  # the opt-in GEMM variants that lost their A/B (csrc/wd_gemm.hip)
     FLAGS.append("-DWDIFF_EXPERIMENTAL")
 if os.environ.get("WDIFF_STAMPS", "0") != "0":  # s_memtime stamps inside wd_dw_kernel / wd_gemmw_kernel (tools/*_bench.py --stamps)
-    FLAGS += ["-DWD_DW_STAMPS", "-DWD_GEMMW_STAMPS"]
+    FLAGS += ["-DWD_DW_STAMPS", "-DWD_GEMMW_STAMPS", "-DWD_Q_STAMPS"]
 
 
 def _hipcc() -> str:

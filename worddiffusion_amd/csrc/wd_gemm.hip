@@ -2235,9 +2235,11 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     if (a.ksplit < 0 || a.ksplit > WD_MAX_KSPLIT) return WD_EINVAL;
     if (a.w_layout == 3) {
         // fragment-major weights (wd_gemm_pack_w): the 64 x 320 weights-to-registers kernel only
-        if (a.n % 160 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160) || a.ktot % 64) return WD_EINVAL;
+        if (a.n % 80 || a.act == WD_ACT_GEGLU || (a.tile && a.tile != 64320 && a.tile != 128160 && a.tile != 64080) || a.ktot % 64)
+            return WD_EINVAL;
         if (a.tile == 0) a.tile = (a.a32 || a.ln_gamma) ? 64320 : 128160;
         if (a.n % (a.tile % 1000)) return WD_EINVAL;
+        if (a.tile == 64080) a.ksplit = 1;  // (all of K inside the workgroup: wd_gemmq_kernel; wd_gemmq_applies() is checked at the dispatch)
     }
     if (a.stat_part) {
         // fused GroupNorm statistics need row panels that tile the samples and whole groups inside a column tile
@@ -2261,7 +2263,7 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
     }
     if (a.gn_gamma) {
         // GroupNorm of the result in the combine launch (wd_reduce_gn_tile): whole (sample, group) blocks per 64 x 40 tile
-        if (!a.gn_beta || !a.stat_part || !a.out_hi || !a.ws || a.hw_out != 64 || a.m % 64 || a.n % 160 || a.gn_cpg <= 0 ||
+        if (!a.gn_beta || !a.stat_part || !a.out_hi || (!a.ws && a.tile != 64080) || a.hw_out != 64 || a.m % 64 || a.n % 160 || a.gn_cpg <= 0 ||
             40 % a.gn_cpg || a.stat_cpg <= 0 || a.gn_cpg % a.stat_cpg || a.act != WD_ACT_NONE || a.resid_rows || a.w_layout == 1)
             return WD_EINVAL;
         if (((a.out_ld | a.rowvec_ld | a.resid_ld | a.out_pl_ld) & 3) ||
@@ -2316,11 +2318,16 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         const wd_src& q0 = a.src[0];
         const bool same3 = q0.ntaps == 9 && q0.gather && a.slab_rows > 0 && q0.hw_src == a.hw_out && a.hw_out % a.slab_rows == 0;
         if (!same3) a.slab_rows = 0;  // (slab_rows: the image width of a 3x3 / pad 1 / stride 1 source, as for w_layout 2)
+        a.tickets = nullptr;
+        if (a.tile == 64080) {
+            if (!wd_gemmq_applies(a)) return WD_EINVAL;
+            if (a.gn_gamma && (40 % a.gn_cpg || 80 % a.gn_cpg)) return WD_EINVAL;
+            return wd_gemmq_launch(a, st);
+        }
         const int nk64 = a.ktot / 64;
         if (a.ksplit == 0) a.ksplit = a.ws ? wd_auto_ksplit(a.tile, a.m, a.n, nk64, a.ws_floats) : 1;
         if (a.ksplit > 1 && (nk64 < a.ksplit || (long)a.ksplit * a.m * a.n > a.ws_floats)) a.ksplit = 1;
         if (a.gn_gamma && a.ksplit <= 1) return WD_EINVAL;
-        a.tickets = nullptr;
         return wd_gemmw_launch(a, st);
     }
 #ifndef WDIFF_EXPERIMENTAL

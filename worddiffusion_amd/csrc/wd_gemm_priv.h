@@ -7,3 +7,6 @@
 int wd_gemmw_launch(const wd_gemm_args& a, hipStream_t st);
 // wd_gemm.hip: the split-K combine launch for slabs of a launch with bm-row tiles (statistics layout follows bm).
 int wd_gemm_launch_reduce(const wd_gemm_args& a, hipStream_t st, int bm);
+// wd_gemmq.hip: 64 x 80 tiles, all of K inside the workgroup (wd_gemm_args.tile == 64080: the 3x3 layers over 64-position samples).
+bool wd_gemmq_applies(const wd_gemm_args& a);
+int wd_gemmq_launch(const wd_gemm_args& a, hipStream_t st);

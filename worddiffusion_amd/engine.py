@@ -303,6 +303,7 @@ class UNetEngine:
         # 64 x 320 tiles with the weights loaded straight into the MFMA operand registers (csrc/wd_gemmw.hip): the 320-column
         # layers whose grid fills the chip without a K cut
         self.use_wdirect = os.environ.get("WDIFF_GEMM_WDIRECT", "1") != "0"
+        self.use_smallmap = os.environ.get("WDIFF_GEMM_SMALLMAP", "1") != "0"  # 64 x 80 whole-K tiles for 3x3 layers over 64-position samples
         # GEGLU feed-forward + residual in one launch per 64-token panel, hidden activations on chip (csrc/wd_ff.hip)
         self.fuse_ff = os.environ.get("WDIFF_FUSE_FF", "1") != "0"
         self.fuse_proj = os.environ.get("WDIFF_FUSE_PROJ", "1") != "0"   # ... and proj_out + residual in the same launch
@@ -584,6 +585,12 @@ class UNetEngine:
                    # (the K-cut layers of the 4 x 16 level stay on the LDS-staged kernel: this one is 5 % faster on their long loops
                    # in isolation and 2 % slower inside the step)
                    ((m + 63) // 64) * (nrows // 320) >= 256)
+        # 3x3 layers over 64-position samples (the 4 x 16 level): 64 x 80 tiles with all of K inside the workgroup (wd_gemmq_kernel) instead
+        # of a K cut over workgroups + combine launch
+        smallmap = (self.use_smallmap and not wdirect and not span and not self.use_conv3 and a32 is None and ln is None and
+                    w_row_off == 0 and n is None and act == N.ACT_NONE and tile == 0 and self.npass == 3 and len(srcs) == 1 and
+                    srcs[0].ntaps == 9 and getattr(srcs[0], "_same_w", 0) in (16, 32) and hw_out == 64 and srcs[0].hw_src == 64 and
+                    m % 64 == 0 and nrows % 80 == 0 and srcs[0].c % 64 == 0 and not resid_rows and (m // 64) * (nrows // 80) >= 128)
         assert a32 is None or wdirect, what
         if a32 is not None:
             x32, gname, eps, silu = a32
@@ -592,7 +599,12 @@ class UNetEngine:
             a.a32_nchunk, a.a32_pcpg, a.a32_cpg = nchunk, pc, x32.c // 32
             a.a32_gamma, a.a32_beta = self._w[gname + ".g"].data_ptr(), self._w[gname + ".b"].data_ptr()
             a.a32_eps, a.a32_silu = float(eps), int(silu)
-        if wdirect:
+        if smallmap:
+            wf = self._wfrag(wname)
+            a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
+            a.w_layout, a.slab_rows = 3, srcs[0]._same_w
+            tile = 64080
+        elif wdirect:
             wf = self._wfrag(wname)
             a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
             a.w_layout, a.slab_rows = 3, getattr(srcs[0], "_same_w", 0) if srcs[0].ntaps == 9 else 0
@@ -631,8 +643,8 @@ class UNetEngine:
         if want_stats and self.fuse_stats and nrows % 32 == 0 and (hw_out % 128 == 0 or hw_out == 64):
             cpg = nrows // 32
             bn = (tile % 1000) if tile else (160 if nrows % 160 == 0 else 64)
-            if bn % cpg == 0 and (tile == 0 or tile // 1000 == 128 or wdirect) and not span:
-                nchunk = max(1, hw_out // (64 if wdirect else 128))  # (the statistics are kept per row panel of the tile)
+            if bn % cpg == 0 and (tile == 0 or tile // 1000 == 128 or wdirect or smallmap) and not span:
+                nchunk = max(1, hw_out // (64 if (wdirect or smallmap) else 128))  # (the statistics are kept per row panel of the tile)
                 part = torch.zeros((m // hw_out, nchunk, 32, 2), dtype=torch.float64, device=self.device)
                 self._cur_plan.keep.append(part)
                 a.stat_part, a.stat_cpg = part.data_ptr(), cpg
@@ -779,6 +791,8 @@ class UNetEngine:
             return False
         if pr.act != N.ACT_NONE or pr.resid_rows or pr.ksplit != 0 or pr.w_layout == 1 or pr.dbg:
             return False
+        if pr.tile == 64080:  # all of K in the producer's workgroups (wd_gemmq_kernel): the norm runs in its own epilogue
+            return pr.w_layout == 3
         if pr.tile != (64320 if pr.w_layout == 3 else 0):
             return False
         return self.lib.wd_gemm_auto_ksplit(pr.m, pr.n, pr.ktot, pr.ws_floats) > 1
