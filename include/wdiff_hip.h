@@ -79,11 +79,15 @@ typedef struct wd_gemm_args {
     wd_bf16* out_hi;      /* split-bf16 planes of the result for the next GEMM, or NULL */
     wd_bf16* out_lo;
     int32_t out_pl_ld;
-    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128128, 128160, 64064; 64320 with w_layout 3) */
+    int32_t tile;         /* 0 = auto; else BM*1000+BN of a compiled tile (128064, 128128, 128160, 64064; 64320 / 64080 with w_layout 3) */
     int32_t w_layout;     /* 0: w = [n][ktot].  1: "slab order" [stage][n][32], stage = (32-channel chunk, tap) of src0
                            * (chunk-major, tap-minor) followed by the 32-channel chunks of src1: selects the kernel that
                            * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2)
-                           * 3: fragment-major weights (wd_gemm_pack_w), loaded straight into registers; tile 64320 or 128160.
+                           * 3: fragment-major weights (wd_gemm_pack_w), loaded straight into registers; tile 64320 or 128160; or tile
+                           *    64080 - all of K inside the workgroup, never a K cut: src[0] a 3x3 / pad 1 / stride 1 source over
+                           *    64-position samples of width slab_rows (16 or 32; hw_out == hw_src == 64) or an identity source, src[1]
+                           *    (optional) an identity source, planes only, npass 3, n % 80 == 0, no activation / row gather / a32 / ln;
+                           *    gn_* is then served by the launch itself (n % 160 == 0, 40 % gn_cpg == 0), ws is not needed.
                            *    Statistics (stat_part) are kept per row panel of the tile: nchunk = max(1, hw_out / 64) for the
                            *    64-row tile */
     int32_t slab_rows;    /* w_layout 1: max over 128-row panels of (max - min + 1) gathered source row; <= 192

@@ -1023,6 +1023,47 @@ def test_gn_silu_conv3x3_few_output_channels(B, h, w, c, oc, silu):
                                                                (16, 640, 320, 10, 1, True, False, 16), (3, 128, 160, 40, 1, False, False, 32),
                                                                (7, 384, 480, 10, 0, False, True, 16)])
 def test_gemm_small_maps_whole_k_in_the_workgroup(B, cin, cout, cpg, silu, film, resid, w):
+    _small_maps_case(B, cin, cout, cpg, silu, film, resid, w, 0)
+
+
+@pytest.mark.parametrize("B,cin,cskip,cout", [(64, 320, 640, 320), (3, 64, 128, 160)])
+def test_gemm_small_maps_conv_plus_identity_skip_source(B, cin, cskip, cout):
+    _small_maps_case(B, cin, cout, 10, 1, True, False, 16, cskip)
+
+
+@pytest.mark.parametrize("m,k,n,resid", [(4096, 1280, 320, True), (4096, 320, 320, True), (640, 64, 160, False)])
+def test_gemm_small_maps_linear_layers(m, k, n, resid):
+    """tile 64080 with an identity source only (1x1 / linear layers of the 4 x 16 level): 64 x 80 tiles, K over the waves."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g)
+    wt = torch.randn(n, k, generator=g) / k ** 0.5
+    bias = torch.randn(n, generator=g)
+    rs = torch.randn(m, n, generator=g) if resid else None
+    ref = x.double() @ wt.double().t() + bias.double() + (rs.double() if resid else 0)
+    pl, wp = planes_of(x.to(DEV)), planes_of(wt.to(DEV))
+    wf = torch.empty_like(wp)
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), n, k, wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    a = N.WdGemmArgs()
+    s0 = N.WdSrc()
+    s0.hi, s0.lo, s0.ld, s0.c, s0.ntaps = pl[0].data_ptr(), pl[1].data_ptr(), k, k, 1
+    a.src[0] = s0
+    a.nsrc, a.npass = 1, 3
+    a.w_hi, a.w_lo, a.w_layout, a.tile = wf[0].data_ptr(), wf[1].data_ptr(), 3, 64080
+    a.m, a.n, a.ktot, a.hw_out = m, n, k, 64
+    bd, out, opl = bias.to(DEV), torch.full((m, n), float("nan"), device=DEV), torch.zeros(2, m, n, dtype=torch.bfloat16, device=DEV)
+    a.bias, a.out_f32, a.out_ld = bd.data_ptr(), out.data_ptr(), n
+    a.out_hi, a.out_lo, a.out_pl_ld = opl[0].data_ptr(), opl[1].data_ptr(), n
+    if resid:
+        rd = rs.to(DEV)
+        a.resid, a.resid_ld = rd.data_ptr(), n
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm 64080 linear")
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), ref) < 2e-5
+    assert max_rel(unplanes(opl).cpu(), ref) < 2e-5
+
+
+def _small_maps_case(B, cin, cout, cpg, silu, film, resid, w, cskip):
     """wd_gemm_args.tile = 64080 (wd_gemmq_kernel): 3x3 convolution over 64-position samples, 64 x 80 tiles, the input rows kept in
     LDS, the eight waves splitting K - plain epilogue (bias / FiLM / residual / statistics / planes of the result) and with the
     consumer's GroupNorm (+SiLU) in the same launch, vs fp64 torch and vs the default kernel."""
@@ -1037,6 +1078,10 @@ def test_gemm_small_maps_whole_k_in_the_workgroup(B, cin, cout, cpg, silu, film,
     rs = torch.randn(m, cout, generator=g) if resid else None
     gam, bet = torch.randn(cout, generator=g) * 0.2 + 1, torch.randn(cout, generator=g) * 0.2
     ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    xs = torch.randn(B, cskip, h, w, generator=g) if cskip else None     # the 1x1 skip convolution of a decoder block as a second source
+    ws = torch.randn(cout, cskip, generator=g) / max(cskip, 1) ** 0.5 if cskip else None
+    if cskip:
+        ref = ref + F.conv2d(xs.double(), ws.double()[:, :, None, None])
     if film:
         ref = ref + fl.double()[:, :, None, None]
     if resid:
@@ -1047,9 +1092,13 @@ def test_gemm_small_maps_whole_k_in_the_workgroup(B, cin, cout, cpg, silu, film,
     tok = lambda t: t.permute(0, 2, 3, 1).reshape(m, -1)  # noqa: E731
     tab, _, _ = conv_gather_table(h, w, "same")
     pl = planes_of(tok(x).contiguous().to(DEV))
-    wp = planes_of(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(DEV))
+    pls = planes_of(tok(xs).contiguous().to(DEV)) if cskip else None
+    wcat = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+    if cskip:
+        wcat = torch.cat([wcat, ws], 1)
+    wp = planes_of(wcat.contiguous().to(DEV))
     wf = torch.empty_like(wp)
-    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), cout, 9 * cin, wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), cout, wcat.shape[1], wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
     tabd = torch.from_numpy(tab).to(DEV)
     pc = 10 if cpg % 10 == 0 else cpg
 
@@ -1060,11 +1109,16 @@ def test_gemm_small_maps_whole_k_in_the_workgroup(B, cin, cout, cpg, silu, film,
         s.ld, s.c, s.ntaps, s.hw_src = cin, cin, 9, hw
         a.src[0] = s
         a.nsrc, a.npass = 1, 3
+        if cskip:
+            s1 = N.WdSrc()
+            s1.hi, s1.lo, s1.ld, s1.c, s1.ntaps = pls[0].data_ptr(), pls[1].data_ptr(), cskip, cskip, 1
+            a.src[1] = s1
+            a.nsrc = 2
         if small:
             a.w_hi, a.w_lo, a.w_layout, a.tile, a.slab_rows = wf[0].data_ptr(), wf[1].data_ptr(), 3, 64080, w
         else:
             a.w_hi, a.w_lo = wp[0].data_ptr(), wp[1].data_ptr()
-        a.m, a.n, a.ktot, a.hw_out = m, cout, 9 * cin, hw
+        a.m, a.n, a.ktot, a.hw_out = m, cout, 9 * cin + cskip, hw
         keep = dict(bias=bias.to(DEV), out=torch.full((m, cout), float("nan"), device=DEV),
                     opl=torch.zeros(2, m, cout, dtype=torch.bfloat16, device=DEV), ws=torch.empty(8 * m * cout, device=DEV),
                     part=torch.zeros(B, 1, cout // pc, 2, dtype=torch.float64, device=DEV), gam=gam.to(DEV), bet=bet.to(DEV))

@@ -51,71 +51,19 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
 
-    const int W = a.slab_rows, H = a.hw_out / W;
-    const int wsh = __builtin_ctz(W);
-    const int TR = QBM >> wsh;                 // image rows of the tile
+    // geometry of a 3x3 source (W = 0: there is none - 1x1 / linear layers)
+    const int W = a.src[0].ntaps == 9 ? a.slab_rows : 0;
+    const int wsh = W ? __builtin_ctz(W) : 0;
+    const int H = W ? a.hw_out >> wsh : 0;
+    const int TR = W ? QBM >> wsh : 0;         // image rows of the tile
     const int SW = W + 2;                      // slab tokens per image row
-    const int SLR = (TR + 2) * SW;             // slab rows per chunk
-    const int CPL = SLR * 128;                 // one plane of one chunk
-    const int CHB = 2 * CPL;                   // one chunk: hi plane, lo plane
-    const int bsm = m0 / a.hw_out;             // sample of the tile (hw_out == 64)
-    const int y0 = (m0 - bsm * a.hw_out) >> wsh;
-    const int cpt0 = a.src[0].c >> 6;          // 64-channel chunks of the source
-    const int npass = (cpt0 + nchp - 1) / nchp;
+    const int bsm = m0 / a.hw_out;             // sample of the tile (3x3 source: hw_out == 64)
+    const int y0 = W ? (m0 - bsm * a.hw_out) >> wsh : 0;
 
     auto make_srd = [](const void* p) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFF0, 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t srd_w_hi = make_srd(a.w_hi), srd_w_lo = make_srd(a.w_lo);
-    const __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(a.src[0].hi), srd_a_lo = make_srd(a.src[0].lo);
-
-    // ---- the padding tokens of every chunk (left / right end of every slab image row), both planes: zero for the whole launch
-    for (int i = tid; i < nchp * 2 * (TR + 2) * 2 * 8; i += QNT) {
-        const int pc = i & 7, side = (i >> 3) & 1;
-        int rest = i >> 4;
-        const int ry = rest % (TR + 2);
-        rest /= (TR + 2);
-        const int pl = rest & 1, ch = rest >> 1;
-        const int row = ry * SW + (side ? SW - 1 : 0);
-        *reinterpret_cast<q_u32x4*>(smem + ch * CHB + pl * CPL + row * 128 + pc * 16) = q_u32x4{0u, 0u, 0u, 0u};
-    }
-
-    // ---- slab fill: item = (chunk, plane, slab token, 16-byte piece), one per thread and round, through registers (ordinary loads
-    // and LDS stores: an LDS-DMA here would make hipcc guard every LDS read of the loop with vmcnt(0) - and the loop keeps weight
-    // loads in flight).  Rows above / below the image carry an out-of-range offset: zeros.
-    const int ntok = (TR + 2) * W;             // real tokens of a slab
-    auto fill = [&](const int pass) {
-        const int c_lo = pass * nchp, nch = min(nchp, cpt0 - c_lo);
-        const int nitems = nch * ntok * 8;     // per plane
-        // (all the loads of a round are in flight before the first store: at most 8 items per thread and plane - 5 chunks x 136
-        // tokens x 8 pieces / 512 - i.e. one round trip for the whole slab instead of one per four items)
-        for (int i0 = 0; i0 < nitems; i0 += 8 * QNT) {
-            q_u32x4 v[2][8];
-            int dst[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * QNT + tid;
-                const int pc = i & 7;
-                const int rest = i >> 3;
-                const int chl = rest / ntok, tq = rest - chl * ntok;
-                const int ry = tq >> wsh, x = tq & (W - 1);
-                const int gy = y0 - 1 + ry;
-                const bool ok = i < nitems && gy >= 0 && gy < H;
-                const uint32_t vo = ok ? (uint32_t)(bsm * a.src[0].hw_src + gy * W + x) * (uint32_t)(a.src[0].ld * 2) +
-                                             (uint32_t)((c_lo + chl) * 128 + pc * 16)
-                                       : Q_OOB;
-                v[0][k] = __builtin_amdgcn_raw_buffer_load_b128(srd_a_hi, vo, 0, 0);
-                v[1][k] = __builtin_amdgcn_raw_buffer_load_b128(srd_a_lo, vo, 0, 0);
-                dst[k] = i < nitems ? chl * CHB + q_lds_off(ry * SW + x + 1, pc) : -1;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (dst[k] >= 0) {
-                    *reinterpret_cast<q_u32x4*>(smem + dst[k]) = v[0][k];
-                    *reinterpret_cast<q_u32x4*>(smem + dst[k] + CPL) = v[1][k];
-                }
-        }
-    };
 
     // ---- weights: fragment-major, this tile's five column tiles of a k-step are 5 KB in a row
     const int nct = a.n >> 4;
@@ -137,30 +85,21 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
         for (int t = 0; t < 5; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
-    // slab row of (row tile i, lane row 0) for the centre tap - wave-uniform: 16 consecutive output positions are 16 consecutive slab rows
-    int srs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = 16 * i;
-        srs[i] = ((p >> wsh) + 1) * SW + (p & (W - 1)) + 1;
-    }
-    auto mfma_step = [&](const int chl, const int tap, const int half, const bf16x8 (&fb)[5][2]) {
-        const int ky = tap / 3;
-        const int shift = (ky - 1) * SW + (tap - 3 * ky - 1) + l15;
-        const char* base = smem + chl * CHB;
+    // one k-step: A fragments of row tile i from slab rows rb[i] + shift + (lane row), read right before its 15 MFMAs (one tile ahead)
+    auto mfma_step = [&](const char* base, const int cpl, const int (&rb)[4], const int shift, const int half, const bf16x8 (&fb)[5][2]) {
         const int ach = half * 4 + lq;
         bf16x8 xa[2][2];
         {
-            const int ao = q_lds_off(srs[0] + shift, ach);
+            const int ao = q_lds_off(rb[0] + shift + l15, ach);
             xa[0][0] = *reinterpret_cast<const bf16x8*>(base + ao);
-            xa[0][1] = *reinterpret_cast<const bf16x8*>(base + CPL + ao);
+            xa[0][1] = *reinterpret_cast<const bf16x8*>(base + cpl + ao);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < 3) {
-                const int ao = q_lds_off(srs[i + 1] + shift, ach);
+                const int ao = q_lds_off(rb[i + 1] + shift + l15, ach);
                 xa[(i + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(base + ao);
-                xa[(i + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(base + CPL + ao);
+                xa[(i + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(base + cpl + ao);
             }
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
@@ -170,7 +109,6 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
             }
         }
     };
-
 #ifdef WD_Q_STAMPS
     unsigned long long* qst = (a.dbg & 0x100) && a.ws && blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(a.ws) + wave * 8 : nullptr;
 #define Q_STAMP(i) if (qst && lane == 0) qst[i] = __builtin_amdgcn_s_memtime()
@@ -178,52 +116,123 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
 #define Q_STAMP(i)
 #endif
     Q_STAMP(0);
-    bf16x8 xb[5][2], yb[5][2], zb[5][2];
-    for (int pass = 0; pass < npass; ++pass) {
-        const int c_lo = pass * nchp, nch = min(nchp, cpt0 - c_lo);
-        const int nks = 18 * nch;  // k-steps of the pass, chunk-major: ks = 18 chunk + 2 tap + half
-        if (pass > 0) __syncthreads();  // every wave is done with the previous pass's slab
-        fill(pass);
-        __syncthreads();
-        Q_STAMP(1 + 2 * (pass & 1));
-        // this wave's k-steps: wave, wave + 8, ...  State of the NEXT step to load: (chunk nc, position nr = 2 tap + half in the chunk)
-        int nc = 0, nr = wave;     // (wave < 18)
-        auto kabs_of = [&](const int chl, const int r) {  // absolute k-step of the weights: 2 (tap cpt0 + chunk) + half
-            return 2 * ((r >> 1) * cpt0 + c_lo + chl) + (r & 1);
-        };
-        auto advance = [&](int& c, int& r) {
-            r += 8;
-            const bool wrap = r >= 18;
-            r = __builtin_amdgcn_readfirstlane(wrap ? r - 18 : r);
-            c = __builtin_amdgcn_readfirstlane(wrap ? c + 1 : c);
-        };
-        int cc = 0, cr = wave;     // the step to multiply
-        // weights two k-steps ahead (three register sets): one step of lead left the waves waiting on L2 a third of the loop
-        load_b(xb, kabs_of(nc, nr), 18 * nc + nr < nks);
-        advance(nc, nr);
-        load_b(yb, kabs_of(nc, nr), 18 * nc + nr < nks);
-        advance(nc, nr);
-        for (int ks = wave; ks < nks; ks += 24) {
-            load_b(zb, kabs_of(nc, nr), 18 * nc + nr < nks);
-            advance(nc, nr);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(cc, cr >> 1, cr & 1, xb);
-            __builtin_amdgcn_sched_barrier(0);
-            advance(cc, cr);
-            load_b(xb, kabs_of(nc, nr), 18 * nc + nr < nks);
-            advance(nc, nr);
-            __builtin_amdgcn_sched_barrier(0);
-            if (18 * cc + cr < nks) mfma_step(cc, cr >> 1, cr & 1, yb);
-            __builtin_amdgcn_sched_barrier(0);
-            advance(cc, cr);
-            load_b(yb, kabs_of(nc, nr), 18 * nc + nr < nks);
-            advance(nc, nr);
-            __builtin_amdgcn_sched_barrier(0);
-            if (18 * cc + cr < nks) mfma_step(cc, cr >> 1, cr & 1, zb);
-            __builtin_amdgcn_sched_barrier(0);
-            advance(cc, cr);
+    bf16x8 xb[5][2], yb[5][2];
+    bool first_pass = true;
+
+    // One source = passes of up to `pchunks` 64-channel chunks whose rows fit LDS.  CONV: the 3x3 slab ((TR + 2) image rows of W + 2
+    // tokens, zero tokens at the row ends, 18 k-steps per chunk: 2 tap + half).  Identity (1x1 / linear / the skip source of a
+    // decoder block): the tile's own 64 rows, 2 k-steps per chunk.  kbase: the source's first k-step in the weights.
+    auto run_source = [&](const wd_src& q, const bool conv, const int kbase) {
+        const int cpt = q.c >> 6;
+        const int slr = conv ? (TR + 2) * SW : QBM;      // slab rows per chunk
+        const int cpl = slr * 128, chb = 2 * cpl;
+        const int pchunks = min(conv ? 5 : 8, (140 * 1024) / chb);
+        const int kpc = conv ? 18 : 2;                   // k-steps per chunk
+        const int ntok = conv ? (TR + 2) * W : QBM;      // real tokens of a slab
+        const __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(q.hi), srd_a_lo = make_srd(q.lo);
+        int rb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = 16 * i;
+            rb[i] = conv ? ((p >> wsh) + 1) * SW + (p & (W - 1)) + 1 : p;
         }
-    }
+        for (int c_lo = 0; c_lo < cpt; c_lo += pchunks) {
+            const int nch = min(pchunks, cpt - c_lo);
+            const int nks = kpc * nch;  // k-steps of the pass, chunk-major
+            if (!first_pass) __syncthreads();  // every wave is done with the previous slab
+            first_pass = false;
+            if (conv) {  // the padding tokens (left / right end of every slab image row), both planes
+                for (int i = tid; i < nch * 2 * (TR + 2) * 2 * 8; i += QNT) {
+                    const int pc = i & 7, side = (i >> 3) & 1;
+                    int rest = i >> 4;
+                    const int ry = rest % (TR + 2);
+                    rest /= (TR + 2);
+                    const int pl = rest & 1, ch = rest >> 1;
+                    const int row = ry * SW + (side ? SW - 1 : 0);
+                    *reinterpret_cast<q_u32x4*>(smem + ch * chb + pl * cpl + row * 128 + pc * 16) = q_u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            // slab fill through registers (ordinary loads and LDS stores: an LDS-DMA here would make hipcc guard every LDS read of the
+            // loop with vmcnt(0) - and the loop keeps weight loads in flight).  All the loads of a round are in flight before its
+            // first store.  Rows above / below the image carry an out-of-range offset: zeros.
+            const int nitems = nch * ntok * 8;  // (chunk, token, 16-byte piece) per plane
+            for (int i0 = 0; i0 < nitems; i0 += 8 * QNT) {
+                q_u32x4 v[2][8];
+                int dst[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * QNT + tid;
+                    const int pc = i & 7;
+                    const int rest = i >> 3;
+                    const int chl = rest / ntok, tq = rest - chl * ntok;
+                    int grow, srow;
+                    bool ok = i < nitems;
+                    if (conv) {
+                        const int ry = tq >> wsh, x = tq & (W - 1);
+                        const int gy = y0 - 1 + ry;
+                        ok = ok && gy >= 0 && gy < H;
+                        grow = bsm * q.hw_src + gy * W + x;
+                        srow = ry * SW + x + 1;
+                    } else {
+                        grow = m0 + tq;
+                        srow = tq;
+                    }
+                    const uint32_t vo = ok ? (uint32_t)grow * (uint32_t)(q.ld * 2) + (uint32_t)((c_lo + chl) * 128 + pc * 16) : Q_OOB;
+                    v[0][k] = __builtin_amdgcn_raw_buffer_load_b128(srd_a_hi, vo, 0, 0);
+                    v[1][k] = __builtin_amdgcn_raw_buffer_load_b128(srd_a_lo, vo, 0, 0);
+                    dst[k] = i < nitems ? chl * chb + q_lds_off(srow, pc) : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (dst[k] >= 0) {
+                        *reinterpret_cast<q_u32x4*>(smem + dst[k]) = v[0][k];
+                        *reinterpret_cast<q_u32x4*>(smem + dst[k] + cpl) = v[1][k];
+                    }
+            }
+            __syncthreads();
+            Q_STAMP(1);
+            // this wave's k-steps: wave, wave + 8, ...  (c, r): chunk of the pass and position in the chunk (CONV: 2 tap + half)
+            auto kabs_of = [&](const int c, const int r) {
+                return kbase + (conv ? 2 * ((r >> 1) * cpt + c_lo + c) + (r & 1) : 2 * (c_lo + c) + r);
+            };
+            auto advance = [&](int& c, int& r) {
+                if (conv) {
+                    r += 8;
+                    const bool wrap = r >= 18;
+                    r = __builtin_amdgcn_readfirstlane(wrap ? r - 18 : r);
+                    c = __builtin_amdgcn_readfirstlane(wrap ? c + 1 : c);
+                } else {
+                    c += 4;
+                }
+            };
+            auto shift_of = [&](const int r) {
+                if (!conv) return 0;
+                const int tap = r >> 1, ky = tap / 3;
+                return (ky - 1) * SW + (tap - 3 * ky - 1);
+            };
+            int nc = conv ? 0 : wave >> 1, nr = conv ? wave : wave & 1;   // the next step to load
+            int cc = nc, cr = nr;                                          // the step to multiply
+            load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);
+            advance(nc, nr);
+            for (int ks = wave; ks < nks; ks += 16) {
+                load_b(yb, kabs_of(nc, nr), kpc * nc + nr < nks);
+                advance(nc, nr);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), cr & 1, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                advance(cc, cr);
+                load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);
+                advance(nc, nr);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kpc * cc + cr < nks) mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), cr & 1, yb);
+                __builtin_amdgcn_sched_barrier(0);
+                advance(cc, cr);
+            }
+        }
+    };
+    const bool conv0 = a.src[0].ntaps == 9;
+    run_source(a.src[0], conv0, 0);
+    if (a.nsrc > 1) run_source(a.src[1], false, 2 * a.src[0].ntaps * (a.src[0].c >> 6));
 
     Q_STAMP(4);
     // ---- the eight partial tiles summed in a fixed order: s_j = w_j + w_{j+4}, result = ((s_0 + s_1) + s_2) + s_3.  The partial
@@ -278,30 +287,30 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
 #endif
 }
 
-int q_chunks_per_pass(const int W) {
-    const int chb = 2 * ((64 / W + 2) * (W + 2)) * 128;
-    int n = (140 * 1024) / chb;
-    return n > 5 ? 5 : n;
-}
-
 }  // namespace
 
 // Shapes the kernel serves: one 3x3 / pad 1 / stride 1 source given as planes, 64-position samples of width 16 or 32, 80-column
 // tiles, split-bf16, no K cut, vector epilogue.
 bool wd_gemmq_applies(const wd_gemm_args& a) {
     const int W = a.slab_rows;
-    return a.w_layout == 3 && a.tile == 64080 && !a.a32 && !a.ln_gamma && a.nsrc == 1 && a.src[0].ntaps == 9 && a.src[0].gather &&
-           a.src[0].hi && a.src[0].lo && a.npass == 3 && a.ksplit <= 1 && (W == 16 || W == 32) && a.hw_out == 64 &&
-           a.src[0].hw_src == 64 && a.m % 64 == 0 && a.n % QBN == 0 && a.src[0].c % 64 == 0 && a.act == WD_ACT_NONE && !a.resid_rows &&
-           (a.src[0].ld & 7) == 0;
+    if (!(a.w_layout == 3 && a.tile == 64080 && !a.a32 && !a.ln_gamma && a.npass == 3 && a.ksplit <= 1 && a.m % 64 == 0 && a.n % QBN == 0 &&
+          a.act == WD_ACT_NONE && !a.resid_rows && a.nsrc >= 1 && a.nsrc <= 2))
+        return false;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const wd_src& q = a.src[s];
+        if (!q.hi || !q.lo || q.c % 64 || (q.ld & 7)) return false;
+        const bool conv = s == 0 && q.ntaps == 9 && q.gather && (W == 16 || W == 32) && a.hw_out == 64 && q.hw_src == 64;
+        const bool ident = q.ntaps == 1 && !q.gather;
+        if (!conv && !ident) return false;
+    }
+    return true;
 }
 
 int wd_gemmq_launch(const wd_gemm_args& a, hipStream_t st) {
-    const int W = a.slab_rows;
-    const int nchp = q_chunks_per_pass(W);
-    const int loop_smem = nchp * 2 * ((64 / W + 2) * (W + 2)) * 128;
+    const int loop_smem = 140 * 1024;   // (slabs of a pass: at most 140 KB by construction in the kernel)
     const int red_smem = (QBM * QLDE + 4 * QBN * (QBM + 4)) * 4 + WD_STAT_SCRATCH;
     const int smem = loop_smem > red_smem ? loop_smem : red_smem;
+    const int nchp = 0;
     static int attr_max = 0;
     if (smem > attr_max) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_gemmq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

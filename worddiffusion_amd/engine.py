@@ -587,10 +587,14 @@ class UNetEngine:
                    ((m + 63) // 64) * (nrows // 320) >= 256)
         # 3x3 layers over 64-position samples (the 4 x 16 level): 64 x 80 tiles with all of K inside the workgroup (wd_gemmq_kernel) instead
         # of a K cut over workgroups + combine launch
+        s0 = srcs[0]
+        sm_conv = s0.ntaps == 9 and getattr(s0, "_same_w", 0) in (16, 32) and s0.hw_src == 64
+        sm_ident = s0.ntaps == 1 and not s0.gather
         smallmap = (self.use_smallmap and not wdirect and not span and not self.use_conv3 and a32 is None and ln is None and
-                    w_row_off == 0 and n is None and act == N.ACT_NONE and tile == 0 and self.npass == 3 and len(srcs) == 1 and
-                    srcs[0].ntaps == 9 and getattr(srcs[0], "_same_w", 0) in (16, 32) and hw_out == 64 and srcs[0].hw_src == 64 and
-                    m % 64 == 0 and nrows % 80 == 0 and srcs[0].c % 64 == 0 and not resid_rows and (m // 64) * (nrows // 80) >= 128)
+                    w_row_off == 0 and n is None and act == N.ACT_NONE and tile == 0 and self.npass == 3 and hw_out == 64 and
+                    (sm_conv or sm_ident) and (len(srcs) == 1 or (srcs[1].ntaps == 1 and not srcs[1].gather)) and
+                    m % 64 == 0 and nrows % 80 == 0 and all(q.c % 64 == 0 for q in srcs) and not resid_rows and
+                    128 <= (m // 64) * (nrows // 80) <= 512)
         assert a32 is None or wdirect, what
         if a32 is not None:
             x32, gname, eps, silu = a32
@@ -602,7 +606,7 @@ class UNetEngine:
         if smallmap:
             wf = self._wfrag(wname)
             a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
-            a.w_layout, a.slab_rows = 3, srcs[0]._same_w
+            a.w_layout, a.slab_rows = 3, (srcs[0]._same_w if sm_conv else 0)
             tile = 64080
         elif wdirect:
             wf = self._wfrag(wname)
