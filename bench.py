@@ -460,6 +460,8 @@ CONTRACTION_CLASSES = {
        "the 3x3 convolutions and 1x1 projections of the 8x32 level)",
     10: "wd_ff_kernel<3> (GEGLU feed-forward + residual per 64-token panel, hidden activations on chip)",
     11: "wd_dw_kernel<3> (weight gradients of the training step from the row-major planes, transposed LDS reads)",
+    12: "wd_gemmq_kernel (64x80 tiles, all of K inside the workgroup, input rows kept in LDS, weights straight to registers: the 3x3 and "
+        "linear layers of the 4x16 level)",
 }
 PMC_KEYS = {0: "wd_gemm2_kernel<128, 160, 3, 2, false, true>", 9: "wd_gemmw_kernel<3, 1, false>", 10: "wd_ff_kernel<3, true>"}
 

@@ -551,10 +551,10 @@ int wd_graph_destroy(void* graph_exec);
  * classes: 0 gemm (the LDS-staged wd_gemm2_kernel<128,160,...>), 1 gn_stats, 2 gn_apply, 3 layernorm, 4 attention, 5 other,
  * 6 gemm with other tile shapes, 7 split-K combine pass, 8 the two-workgroups-per-CU gemm kernel (wd_gemm4_kernel),
  * 9 the weights-to-registers gemm (wd_gemmw_kernel, 64 x 320 / 128 x 160 tiles), 10 the fused feed-forward (wd_ff_kernel),
- * 11 the weight-gradient kernel (wd_dw_kernel).
+ * 11 the weight-gradient kernel (wd_dw_kernel), 12 the whole-K kernel of the small maps (wd_gemmq_kernel).
  * wd_prof_collect: gemm_flops = the 2*M*N*K of class 0; wd_prof_collect_flops additionally returns the algorithmic FLOPs
- * (each multiply-add counted once) of every class that declares them (the contraction classes 0, 6, 8, 9, 10, 11). */
-#define WD_NCLASS 12
+ * (each multiply-add counted once) of every class that declares them (the contraction classes 0, 6, 8, 9, 10, 11, 12). */
+#define WD_NCLASS 13
 int wd_prof_enable(int on);
 int wd_prof_collect(double* ms_per_class, int64_t* launches_per_class, double* gemm_flops); /* syncs */
 int wd_prof_collect_flops(double* ms_per_class, int64_t* launches_per_class, double* flops_per_class); /* syncs */

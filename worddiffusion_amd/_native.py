@@ -15,9 +15,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wdiff_hip.h")
 
 WD_OK, WD_EINVAL, WD_ELAUNCH, WD_ESTATE = 0, -1, -2, -3
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
-NCLASS = 12
+NCLASS = 13
 CLASS_NAMES = ("gemm", "gn_stats", "gn_apply", "layernorm", "attention", "other", "gemm_other_tiles", "gemm_splitk_reduce",
-               "gemm_two_per_cu", "gemm_weights_to_registers", "feed_forward_fused", "weight_gradient")
+               "gemm_two_per_cu", "gemm_weights_to_registers", "feed_forward_fused", "weight_gradient", "gemm_small_maps_whole_k")
 
 _vp = C.c_void_p
 _i = C.c_int

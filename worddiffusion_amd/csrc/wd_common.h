@@ -17,6 +17,7 @@
 #define WD_CLS_GEMM_WDIRECT 9 // wd_gemmw_kernel (weights straight to registers)
 #define WD_CLS_FF 10          // wd_ff_kernel (fused GEGLU feed-forward)
 #define WD_CLS_DW 11          // wd_dw_kernel (weight gradients from the row-major planes)
+#define WD_CLS_GEMM_Q 12      // wd_gemmq_kernel (64 x 80 tiles, all of K in the workgroup: the 4 x 16 level)
 
 // ---- profiling hooks (wd_runtime.hip) -------------------------------------------------------------
 extern "C" int wd_prof_is_on();

@@ -319,7 +319,7 @@ int wd_gemmq_launch(const wd_gemm_args& a, hipStream_t st) {
     }
     const int nbn = a.n / QBN, nbm = a.m / QBM;
     {
-        WdLaunchScope scope(WD_CLS_GEMM_OTHER, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
+        WdLaunchScope scope(WD_CLS_GEMM_Q, st, 2.0 * (double)a.m * (double)a.n * (double)a.ktot);
         hipLaunchKernelGGL(wd_gemmq_kernel, dim3(nbn * nbm), dim3(QNT), smem, st, a, nbn, nbm, nchp);
     }
     return wd_check_launch();
