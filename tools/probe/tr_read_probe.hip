@@ -1,3 +1,5 @@
+// Prints what ds_read_b64_tr_b16 hands every lane of a wave for a [row][64 x 16-bit] LDS image (the operand layout csrc/wd_dw.hip relies on):
+//   hipcc -O3 --offload-arch=gfx950 tools/probe/tr_read_probe.hip -o tools/probe/tr_read_probe && ./tools/probe/tr_read_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
