@@ -61,7 +61,8 @@ class TrainEngine(UNetEngine):
         # (34 wd_gemm_pack_w launches, 0.16 ms) - and measured no faster on the training forward: 14.62 vs 14.43 ms per step.
         # The fused feed-forward does not keep the hidden activations the backward pass needs.
         self.use_wdirect = os.environ.get("WDIFF_TRAIN_WDIRECT", "0") != "0"
-        self.use_smallmap = False   # (its fragment-major weight images would have to be rebuilt after every optimiser step)
+        # (the fragment-major weight images of the whole-K kernel have to be rebuilt after every optimiser step: wd_gemm_pack_w launches)
+        self.use_smallmap = os.environ.get("WDIFF_TRAIN_SMALLMAP", "1") != "0"   # (forward only; measured -0.085 ms per step with the pack launches)
         self.fuse_ff = self.fuse_proj = False
         self.fuse_gn_in = 0
         self.use_dw = os.environ.get("WDIFF_TRAIN_DW", "1") != "0"  # weight gradients through wd_dw (csrc/wd_dw.hip) where it applies
