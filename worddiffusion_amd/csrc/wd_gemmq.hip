@@ -141,6 +141,29 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
             const int nks = kpc * nch;  // k-steps of the pass, chunk-major
             if (!first_pass) __syncthreads();  // every wave is done with the previous slab
             first_pass = false;
+            // this wave's k-steps: wave, wave + 8, ...  (c, r): chunk of the pass and position in the chunk (CONV: 2 tap + half)
+            auto kabs_of = [&](const int c, const int r) {
+                return kbase + (conv ? 2 * ((r >> 1) * cpt + c_lo + c) + (r & 1) : 2 * (c_lo + c) + r);
+            };
+            auto advance = [&](int& c, int& r) {
+                if (conv) {
+                    r += 8;
+                    const bool wrap = r >= 18;
+                    r = __builtin_amdgcn_readfirstlane(wrap ? r - 18 : r);
+                    c = __builtin_amdgcn_readfirstlane(wrap ? c + 1 : c);
+                } else {
+                    c += 4;
+                }
+            };
+            auto shift_of = [&](const int r) {
+                if (!conv) return 0;
+                const int tap = r >> 1, ky = tap / 3;
+                return (ky - 1) * SW + (tap - 3 * ky - 1);
+            };
+            int nc = conv ? 0 : wave >> 1, nr = conv ? wave : wave & 1;   // the next step to load
+            int cc = nc, cr = nr;                                          // the step to multiply
+            load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);   // (the first weights are on their way while the slab is filled)
+            advance(nc, nr);
             if (conv) {  // the padding tokens (left / right end of every slab image row), both planes
                 for (int i = tid; i < nch * 2 * (TR + 2) * 2 * 8; i += QNT) {
                     const int pc = i & 7, side = (i >> 3) & 1;
@@ -191,29 +214,6 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
             }
             __syncthreads();
             Q_STAMP(1);
-            // this wave's k-steps: wave, wave + 8, ...  (c, r): chunk of the pass and position in the chunk (CONV: 2 tap + half)
-            auto kabs_of = [&](const int c, const int r) {
-                return kbase + (conv ? 2 * ((r >> 1) * cpt + c_lo + c) + (r & 1) : 2 * (c_lo + c) + r);
-            };
-            auto advance = [&](int& c, int& r) {
-                if (conv) {
-                    r += 8;
-                    const bool wrap = r >= 18;
-                    r = __builtin_amdgcn_readfirstlane(wrap ? r - 18 : r);
-                    c = __builtin_amdgcn_readfirstlane(wrap ? c + 1 : c);
-                } else {
-                    c += 4;
-                }
-            };
-            auto shift_of = [&](const int r) {
-                if (!conv) return 0;
-                const int tap = r >> 1, ky = tap / 3;
-                return (ky - 1) * SW + (tap - 3 * ky - 1);
-            };
-            int nc = conv ? 0 : wave >> 1, nr = conv ? wave : wave & 1;   // the next step to load
-            int cc = nc, cr = nr;                                          // the step to multiply
-            load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);
-            advance(nc, nr);
             for (int ks = wave; ks < nks; ks += 16) {
                 load_b(yb, kabs_of(nc, nr), kpc * nc + nr < nks);
                 advance(nc, nr);
