@@ -85,7 +85,8 @@ typedef struct wd_gemm_args {
                            * keeps the source slab of a BM-row panel resident in LDS (3x3 taps re-read LDS, not L2)
                            * 3: fragment-major weights (wd_gemm_pack_w), loaded straight into registers; tile 64320 or 128160; or tile
                            *    64080 - all of K inside the workgroup, never a K cut: src[0] a 3x3 / pad 1 / stride 1 source over
-                           *    64-position samples of width slab_rows (16 or 32; hw_out == hw_src == 64) or an identity source, src[1]
+                           *    64-position samples of width slab_rows (16 or 32; hw_out == hw_src == 64), the stride-2 table of a
+                           *    Downsample onto such samples (slab_rows = 16 = the OUTPUT width, hw_src == 256) or an identity source, src[1]
                            *    (optional) an identity source, planes only, npass 3, n % 80 == 0, no activation / row gather / a32 / ln;
                            *    gn_* is then served by the launch itself (n % 160 == 0, 40 % gn_cpg == 0), ws is not needed.
                            *    Statistics (stat_part) are kept per row panel of the tile: nchunk = max(1, hw_out / 64) for the

@@ -1063,6 +1063,38 @@ def test_gemm_small_maps_linear_layers(m, k, n, resid):
     assert max_rel(unplanes(opl).cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,cin,cout", [(64, 320, 320), (3, 64, 160)])
+def test_gemm_small_maps_stride_two_convolution(B, cin, cout):
+    """tile 64080 over the Downsample convolution (3x3, stride 2, pad 1: 8x32 -> 4x16): the slab holds the nine source rows."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B + cin)
+    h, w = 8, 32
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1)
+    tab, ho, wo = conv_gather_table(h, w, "down")
+    m = B * ho * wo
+    pl = planes_of(x.permute(0, 2, 3, 1).reshape(B * h * w, cin).contiguous().to(DEV))
+    wp = planes_of(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(DEV))
+    wf = torch.empty_like(wp)
+    N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), cout, 9 * cin, wf[0].data_ptr(), wf[1].data_ptr(), _st()), "pack")
+    tabd = torch.from_numpy(tab).to(DEV)
+    a = N.WdGemmArgs()
+    s0 = N.WdSrc()
+    s0.hi, s0.lo, s0.gather = pl[0].data_ptr(), pl[1].data_ptr(), tabd.data_ptr()
+    s0.ld, s0.c, s0.ntaps, s0.hw_src = cin, cin, 9, h * w
+    a.src[0] = s0
+    a.nsrc, a.npass = 1, 3
+    a.w_hi, a.w_lo, a.w_layout, a.tile, a.slab_rows = wf[0].data_ptr(), wf[1].data_ptr(), 3, 64080, wo
+    a.m, a.n, a.ktot, a.hw_out = m, cout, 9 * cin, ho * wo
+    bd, out = bias.to(DEV), torch.full((m, cout), float("nan"), device=DEV)
+    a.bias, a.out_f32, a.out_ld = bd.data_ptr(), out.data_ptr(), cout
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm 64080 stride 2")
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), ref.permute(0, 2, 3, 1).reshape(m, cout)) < 2e-5
+
+
 def _small_maps_case(B, cin, cout, cpg, silu, film, resid, w, cskip):
     """wd_gemm_args.tile = 64080 (wd_gemmq_kernel): 3x3 convolution over 64-position samples, 64 x 80 tiles, the input rows kept in
     LDS, the eight waves splitting K - plain epilogue (bias / FiLM / residual / statistics / planes of the result) and with the

@@ -2317,7 +2317,10 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (!ok) return WD_EINVAL;
         const wd_src& q0 = a.src[0];
         const bool same3 = q0.ntaps == 9 && q0.gather && a.slab_rows > 0 && q0.hw_src == a.hw_out && a.hw_out % a.slab_rows == 0;
-        if (!same3) a.slab_rows = 0;  // (slab_rows: the image width of a 3x3 / pad 1 / stride 1 source, as for w_layout 2)
+        // (slab_rows: the image width of a 3x3 / pad 1 / stride 1 source, as for w_layout 2; tile 64080 also takes the stride-2 table
+        // of a Downsample - hw_src == 4 hw_out -, slab_rows then is the OUTPUT width)
+        const bool down3 = a.tile == 64080 && q0.ntaps == 9 && q0.gather && a.slab_rows > 0 && q0.hw_src == 4 * a.hw_out;
+        if (!same3 && !down3) a.slab_rows = 0;
         a.tickets = nullptr;
         if (a.tile == 64080) {
             if (!wd_gemmq_applies(a)) return WD_EINVAL;

@@ -51,13 +51,17 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
 
-    // geometry of a 3x3 source (W = 0: there is none - 1x1 / linear layers)
-    const int W = a.src[0].ntaps == 9 ? a.slab_rows : 0;
+    // geometry of a 3x3 source (W = 0: there is none - 1x1 / linear layers).  ST = 2: the stride-2 convolution of a Downsample
+    // (hw_src == 4 hw_out: the source image is twice as wide and high; only its top / left padding is ever read)
+    const int W = a.src[0].ntaps == 9 ? a.slab_rows : 0;   // OUTPUT image width
     const int wsh = W ? __builtin_ctz(W) : 0;
-    const int H = W ? a.hw_out >> wsh : 0;
-    const int TR = W ? QBM >> wsh : 0;         // image rows of the tile
-    const int SW = W + 2;                      // slab tokens per image row
-    const int bsm = m0 / a.hw_out;             // sample of the tile (3x3 source: hw_out == 64)
+    const int ST = (W && a.src[0].hw_src == 4 * a.hw_out) ? 2 : 1;
+    const int Ws = W * ST, wss = wsh + ST - 1;              // source image width
+    const int Hs = W ? (a.hw_out >> wsh) * ST : 0;          // source image height
+    const int TR = W ? QBM >> wsh : 0;         // output image rows of the tile
+    const int NR = W ? (TR - 1) * ST + 3 : 0;  // source image rows of the slab: ST y0 - 1 ... ST (y0 + TR - 1) + 1
+    const int SW = Ws + 2;                     // slab tokens per image row (a zero token at either end)
+    const int bsm = m0 / a.hw_out;             // sample of the tile
     const int y0 = W ? (m0 - bsm * a.hw_out) >> wsh : 0;
 
     auto make_srd = [](const void* p) {
@@ -86,8 +90,10 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
     // one k-step: A fragments of row tile i from slab rows rb[i] + shift + (lane row), read right before its 15 MFMAs (one tile ahead)
-    auto mfma_step = [&](const char* base, const int cpl, const int (&rb)[4], const int shift, const int half, const bf16x8 (&fb)[5][2]) {
+    auto mfma_step = [&](const char* base, const int cpl, const int (&rb)[4], const int shift0, const int lm, const int half,
+                         const bf16x8 (&fb)[5][2]) {
         const int ach = half * 4 + lq;
+        const int shift = shift0 + lm * l15 - l15;   // (the reads below add l15)
         bf16x8 xa[2][2];
         {
             const int ao = q_lds_off(rb[0] + shift + l15, ach);
@@ -124,17 +130,18 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
     // decoder block): the tile's own 64 rows, 2 k-steps per chunk.  kbase: the source's first k-step in the weights.
     auto run_source = [&](const wd_src& q, const bool conv, const int kbase) {
         const int cpt = q.c >> 6;
-        const int slr = conv ? (TR + 2) * SW : QBM;      // slab rows per chunk
+        const int slr = conv ? NR * SW : QBM;            // slab rows per chunk
         const int cpl = slr * 128, chb = 2 * cpl;
         const int pchunks = min(conv ? 5 : 8, (140 * 1024) / chb);
         const int kpc = conv ? 18 : 2;                   // k-steps per chunk
-        const int ntok = conv ? (TR + 2) * W : QBM;      // real tokens of a slab
+        const int ntok = conv ? NR * Ws : QBM;           // real tokens of a slab
+        const int lm = conv ? ST : 1;                    // slab rows between neighbouring output positions
         const __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(q.hi), srd_a_lo = make_srd(q.lo);
         int rb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 16 * i;
-            rb[i] = conv ? ((p >> wsh) + 1) * SW + (p & (W - 1)) + 1 : p;
+            rb[i] = conv ? ST * (p >> wsh) * SW + ST * (p & (W - 1)) : p;   // tap (0, 0) of the tile's first position
         }
         for (int c_lo = 0; c_lo < cpt; c_lo += pchunks) {
             const int nch = min(pchunks, cpt - c_lo);
@@ -158,18 +165,18 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
             auto shift_of = [&](const int r) {
                 if (!conv) return 0;
                 const int tap = r >> 1, ky = tap / 3;
-                return (ky - 1) * SW + (tap - 3 * ky - 1);
+                return ky * SW + (tap - 3 * ky);
             };
             int nc = conv ? 0 : wave >> 1, nr = conv ? wave : wave & 1;   // the next step to load
             int cc = nc, cr = nr;                                          // the step to multiply
             load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);   // (the first weights are on their way while the slab is filled)
             advance(nc, nr);
             if (conv) {  // the padding tokens (left / right end of every slab image row), both planes
-                for (int i = tid; i < nch * 2 * (TR + 2) * 2 * 8; i += QNT) {
+                for (int i = tid; i < nch * 2 * NR * 2 * 8; i += QNT) {
                     const int pc = i & 7, side = (i >> 3) & 1;
                     int rest = i >> 4;
-                    const int ry = rest % (TR + 2);
-                    rest /= (TR + 2);
+                    const int ry = rest % NR;
+                    rest /= NR;
                     const int pl = rest & 1, ch = rest >> 1;
                     const int row = ry * SW + (side ? SW - 1 : 0);
                     *reinterpret_cast<q_u32x4*>(smem + ch * chb + pl * cpl + row * 128 + pc * 16) = q_u32x4{0u, 0u, 0u, 0u};
@@ -191,10 +198,10 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
                     int grow, srow;
                     bool ok = i < nitems;
                     if (conv) {
-                        const int ry = tq >> wsh, x = tq & (W - 1);
-                        const int gy = y0 - 1 + ry;
-                        ok = ok && gy >= 0 && gy < H;
-                        grow = bsm * q.hw_src + gy * W + x;
+                        const int ry = tq >> wss, x = tq & (Ws - 1);
+                        const int gy = ST * y0 - 1 + ry;
+                        ok = ok && gy >= 0 && gy < Hs;
+                        grow = bsm * q.hw_src + gy * Ws + x;
                         srow = ry * SW + x + 1;
                     } else {
                         grow = m0 + tq;
@@ -218,13 +225,13 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
                 load_b(yb, kabs_of(nc, nr), kpc * nc + nr < nks);
                 advance(nc, nr);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), cr & 1, xb);
+                mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, xb);
                 __builtin_amdgcn_sched_barrier(0);
                 advance(cc, cr);
                 load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);
                 advance(nc, nr);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kpc * cc + cr < nks) mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), cr & 1, yb);
+                if (kpc * cc + cr < nks) mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, yb);
                 __builtin_amdgcn_sched_barrier(0);
                 advance(cc, cr);
             }
@@ -299,7 +306,8 @@ bool wd_gemmq_applies(const wd_gemm_args& a) {
     for (int s = 0; s < a.nsrc; ++s) {
         const wd_src& q = a.src[s];
         if (!q.hi || !q.lo || q.c % 64 || (q.ld & 7)) return false;
-        const bool conv = s == 0 && q.ntaps == 9 && q.gather && (W == 16 || W == 32) && a.hw_out == 64 && q.hw_src == 64;
+        const bool conv = s == 0 && q.ntaps == 9 && q.gather && a.hw_out == 64 &&
+                          (((W == 16 || W == 32) && q.hw_src == 64) || (W == 16 && q.hw_src == 256));   // stride 1 / the stride-2 table
         const bool ident = q.ntaps == 1 && !q.gather;
         if (!conv && !ident) return false;
     }

@@ -329,6 +329,7 @@ class UNetEngine:
         self._tabs: Dict[tuple, torch.Tensor] = {}
         self._tab_np: Dict[int, np.ndarray] = {}
         self._same_w: Dict[int, int] = {}   # gather table pointer -> image width, for the 3x3 / pad 1 / stride 1 tables
+        self._down_w: Dict[int, int] = {}   # ... -> OUTPUT image width, for the 3x3 / pad 1 / stride 2 tables
         self._ws = None
         self.device = None
 
@@ -533,6 +534,8 @@ class UNetEngine:
             dt = torch.from_numpy(tab).to(self.device)
             self._tabs[key] = (dt, ho, wo)
             self._tab_np[dt.data_ptr()] = tab
+            if mode == "down":
+                self._down_w[dt.data_ptr()] = wo
             if mode == "same":
                 self._same_w[dt.data_ptr()] = w
         return self._tabs[key]
@@ -552,6 +555,7 @@ class UNetEngine:
         s = N.WdSrc()
         s._tab_np = self._tab_np.get(gather.data_ptr()) if gather is not None else None
         s._same_w = self._same_w.get(gather.data_ptr(), 0) if gather is not None else 0
+        s._down_w = self._down_w.get(gather.data_ptr(), 0) if gather is not None else 0
         ld = planes.shape[2]
         s.hi = planes[0].data_ptr() + 2 * col_off
         s.lo = planes[1].data_ptr() + 2 * col_off
@@ -588,7 +592,8 @@ class UNetEngine:
         # 3x3 layers over 64-position samples (the 4 x 16 level): 64 x 80 tiles with all of K inside the workgroup (wd_gemmq_kernel) instead
         # of a K cut over workgroups + combine launch
         s0 = srcs[0]
-        sm_conv = s0.ntaps == 9 and getattr(s0, "_same_w", 0) in (16, 32) and s0.hw_src == 64
+        sm_down = s0.ntaps == 9 and getattr(s0, "_down_w", 0) == 16 and s0.hw_src == 256   # the stride-2 convolution 8x32 -> 4x16
+        sm_conv = (s0.ntaps == 9 and getattr(s0, "_same_w", 0) in (16, 32) and s0.hw_src == 64) or sm_down
         sm_ident = s0.ntaps == 1 and not s0.gather
         smallmap = (self.use_smallmap and not wdirect and not span and not self.use_conv3 and a32 is None and ln is None and
                     w_row_off == 0 and n is None and act == N.ACT_NONE and tile == 0 and self.npass == 3 and hw_out == 64 and
@@ -606,7 +611,7 @@ class UNetEngine:
         if smallmap:
             wf = self._wfrag(wname)
             a.w_hi, a.w_lo = wf[0].data_ptr(), wf[1].data_ptr()
-            a.w_layout, a.slab_rows = 3, (srcs[0]._same_w if sm_conv else 0)
+            a.w_layout, a.slab_rows = 3, (16 if sm_down else srcs[0]._same_w if sm_conv else 0)
             tile = 64080
         elif wdirect:
             wf = self._wfrag(wname)
