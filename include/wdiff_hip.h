@@ -370,11 +370,14 @@ int wd_adamw_multi(const void* table, int ntensor, int64_t total_chunks, double 
                    double weight_decay, int64_t step, int ema_mode, double ema_beta, void* stream);
 
 /* Table-driven weight repack (one launch refreshes every packed operand after an optimiser step; the reference reads
- * its parameters in place, unet.py forward).  Entry layout (wd_repack_entry_bytes() = 72 bytes, little endian):
- *   u64 src0, u64 src1 (0 = none), u64 dst_hi, u64 dst_lo, i32 N, C, T, mode, i32 npad, ld, g, ntile_c, i64 chunk0
+ * its parameters in place, unet.py forward).  Entry layout (wd_repack_entry_bytes() = 80 bytes, little endian):
+ *   u64 src0, u64 src1 (0 = none), u64 dst_hi, u64 dst_lo, i32 N, C, T, mode, i32 npad, ld, g, ntile_c, i64 chunk0,
+ *   i32 row_off, col_off (mode 3 only)
  * mode 0: dst[perm_g(n)][t*C + c]   = split(src0[n][c][t])   (forward operand; perm_g = GEGLU x|gate interleave, g=0 none)
  * mode 1: dst[c][t*npad + n]        = split(src0[n][c][t]), 0 for N <= n < npad   (data-gradient operand)
  * mode 2: dstf[perm_g(i)]           = src0[i] (+ src1[i]), i < N   (fp32 vectors)
+ * mode 3: mode 0's matrix written fragment-major (the image wd_gemm_pack_w makes of it); dst = the image's base, ld = the matrix's
+ *         row count (% 16 == 0), the piece sits at (row_off, col_off); needs C % 32 == 0, T in {1, 9}, even col_off
  * dst pointers are pre-offset to the piece's (row, column) origin; ld = row pitch in elements.  A mode-0/1 piece owns
  * ceil(N or npad / tile) * ceil(C / tile) chunks (tile = wd_repack_tile()), a mode-2 piece ceil(N / wd_repack_vchunk()). */
 int wd_repack_entry_bytes(void);

@@ -414,6 +414,31 @@ def test_device_repack_equals_host_specification(variant, train):
         assert torch.equal(got[0], want.to(torch.bfloat16)) if got.dtype == torch.bfloat16 else torch.equal(got, want), name
 
 
+def test_device_repack_writes_the_fragment_major_images_itself():
+    """The fragment-major weight images (wd_gemm_pack_w's layout, read by the weights-to-registers kernels) come out of the same
+    wd_repack_multi launch (mode 3) after a parameter update: bit-identical to packing the refreshed planes."""
+    m = build(DEEP, "base", False, seed=6)
+    eng = m.engine
+    eng.refresh_weights()
+    book = eng._recipes()
+    names = [n for n, r in book.items() if book.frag_ok(r)]
+    kinds = {tuple(sorted({(pc[5], pc[6] > 0, pc[7] > 0, pc[9] > 0) for pc in book[n].pieces})) for n in names}
+    assert len(names) > 20 and len(kinds) >= 3  # 3x3 and 1x1 pieces, pieces at a column offset, GEGLU-interleaved rows
+    for n in names:
+        eng._wfrag(n)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.mul_(1.25)
+    eng.refresh_weights()
+    assert eng._pack[4] == []
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    for n in names:
+        want = torch.empty_like(eng._wf[n])
+        eng._pack_wf(n, want, st)
+        torch.cuda.synchronize()
+        assert torch.equal(eng._wf[n], want), n
+
+
 def _make_train_setup(cfg, seed, ema=True, **kw):
     from worddiffusion_amd.optim import FusedAdamW
     from worddiffusion_amd.training import TrainStep

@@ -12,9 +12,10 @@ struct PackRef {        // one piece of one packed operand; built once by the ho
     const float* src1;  // optional second addend (vectors only: conv bias + skip bias)
     void* dst_hi;       // planes: bf16 hi plane, already offset to (row_off, col_off); vectors: fp32 destination
     void* dst_lo;
-    int32_t N, C, T, mode;     // mode 0: forward planes, 1: data-gradient planes, 2: fp32 vector
+    int32_t N, C, T, mode;     // mode 0: forward planes, 1: data-gradient planes, 2: fp32 vector, 3: forward planes, fragment-major
     int32_t npad, ld, g, ntile_c;
     int64_t chunk0;     // index of this piece's first chunk (tile)
+    int32_t row_off, col_off;  // mode 3 only (dst_hi / dst_lo are the image's base there, ld = the matrix's row count)
 };
 
 constexpr int PT = 32;          // tile: 32 output channels x 32 input channels x T taps
@@ -43,7 +44,24 @@ __device__ __forceinline__ void repack_full_tile(const PackRef& e, float* s, con
     uint32_t* dh = reinterpret_cast<uint32_t*>(e.dst_hi);
     uint32_t* dl = reinterpret_cast<uint32_t*>(e.dst_lo);
     const int pr = tid & 15, r0 = tid >> 4;  // pr: element pair inside the 32-wide run, r0: one of 16 run lanes
-    if (e.mode == 0) {
+    if (e.mode == 3) {
+        // the fragment-major image of mode 0's matrix (wd_gemm_pack_w): 16-byte chunk ((k / 32) * rows / 16 + row / 16) * 64 +
+        // (row & 15) + 16 * ((k / 8) & 3) holds elements k & ~7 .. of the row; 16 consecutive rows x 16 bytes are contiguous
+        const int nct = e.ld >> 4;
+        for (int r = r0; r < PT * T; r += 16) {
+            const int nl = r / T, t = r - nl * T;
+            const int n = n0 + nl;
+            if (n >= N) continue;
+            uint32_t h0, l0, h1, l1;
+            wd_split1(s[nl * ROW + (2 * pr) * T + t], h0, l0);
+            wd_split1(s[nl * ROW + (2 * pr + 1) * T + t], h1, l1);
+            const int row = geglu_perm(n, N, e.g) + e.row_off;
+            const int k = e.col_off + t * C + c0 + 2 * pr;
+            const int64_t o = ((((int64_t)(k >> 5) * nct + (row >> 4)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) >> 1;
+            dh[o] = h0 | (h1 << 16);
+            if (dl) dl[o] = l0 | (l1 << 16);
+        }
+    } else if (e.mode == 0) {
         // dst[perm(n)][t * C + c]: c fastest -> runs of 32 channels per (n, t)
         for (int r = r0; r < PT * T; r += 16) {
             const int nl = r / T, t = r - nl * T;
@@ -96,7 +114,7 @@ __global__ void __launch_bounds__(256) repack_multi_kernel(const PackRef* __rest
     const int n0 = (int)(lc / e.ntile_c) * PT, c0 = (int)(lc % e.ntile_c) * PT;
     const int nc = min(PT, C - c0);           // valid input channels in this tile
     const int row = PT * T + 1;
-    if (nc == PT && (T == 9 || T == 1) && (e.mode == 0 || e.npad - n0 >= PT) && (C & 1) == 0 && (e.ld & 1) == 0 &&
+    if (nc == PT && (T == 9 || T == 1) && (e.mode != 1 || e.npad - n0 >= PT) && (C & 1) == 0 && (e.ld & 1) == 0 &&
         (e.npad & 1) == 0 && ((reinterpret_cast<uintptr_t>(e.dst_hi) | reinterpret_cast<uintptr_t>(e.dst_lo)) & 3) == 0) {
         // full tile: every index below is a shift / a division by a compile-time constant (the generic path spends ~100
         // instructions per element on run-time div / mod), and the planes are written two elements (4 bytes) at a time
@@ -104,6 +122,7 @@ __global__ void __launch_bounds__(256) repack_multi_kernel(const PackRef* __rest
         else repack_full_tile<1>(e, s, n0, c0, tid);
         return;
     }
+    if (e.mode == 3) return;  // (wd_repack_multi's caller only builds mode-3 pieces of full tiles: C % 32 == 0, T in {1, 9})
     // load: for each output channel the (c, t) block is contiguous in the OIHW source
     for (int idx = tid; idx < PT * nc * T; idx += 256) {
         const int nl = idx / (nc * T), rem = idx - nl * (nc * T);

@@ -213,10 +213,18 @@ class RecipeBook(dict):
         if lin.bias is not None:
             self.vector(name + ".b", lin.bias)
 
-    def device_table(self, lib, dst: Dict[str, torch.Tensor], dev):
-        """Serialises the pieces into the entry table of ``wd_repack_multi`` (include/wdiff_hip.h)."""
+    @staticmethod
+    def frag_ok(r) -> bool:
+        """Can ``wd_repack_multi`` write this matrix fragment-major itself (mode 3)?"""
+        return r.planes and r.rows % 16 == 0 and r.cols % 32 == 0 and all(
+            mode == 0 and c % 32 == 0 and t in (1, 9) and col_off % 2 == 0 and row_off >= 0
+            for (mode, p, p2, n, c, t, row_off, col_off, npad, g) in r.pieces)
+
+    def device_table(self, lib, dst: Dict[str, torch.Tensor], dev, frag: Optional[Dict[str, torch.Tensor]] = None):
+        """Serialises the pieces into the entry table of ``wd_repack_multi`` (include/wdiff_hip.h).  ``frag``: name -> the
+        fragment-major image to write as well (mode 3) for the matrices ``frag_ok`` accepts."""
         import struct
-        assert lib.wd_repack_entry_bytes() == 72
+        assert lib.wd_repack_entry_bytes() == 80
         tile, vchunk = lib.wd_repack_tile(), lib.wd_repack_vchunk()
         recs, c0 = [], 0
         for name, r in self.items():
@@ -232,9 +240,14 @@ class RecipeBook(dict):
                     hi, lo = d[0].data_ptr() + o, d[1].data_ptr() + o
                     ntc = (c + tile - 1) // tile
                     nch = (((npad if mode == 1 else n) + tile - 1) // tile) * ntc
-                recs.append(struct.pack("<QQQQiiiiiiiiq", p.data_ptr(), p2.data_ptr() if p2 is not None else 0, hi, lo, n, c, t,
-                                        mode, npad, ld, g, ntc, c0))
+                recs.append(struct.pack("<QQQQiiiiiiiiqii", p.data_ptr(), p2.data_ptr() if p2 is not None else 0, hi, lo, n, c, t,
+                                        mode, npad, ld, g, ntc, c0, 0, 0))
                 c0 += nch
+                if frag is not None and name in frag and self.frag_ok(r):
+                    f = frag[name]
+                    recs.append(struct.pack("<QQQQiiiiiiiiqii", p.data_ptr(), 0, f[0].data_ptr(), f[1].data_ptr(), n, c, t, 3, 0,
+                                            r.rows, g, ntc, c0, row_off, col_off))
+                    c0 += nch
         raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
         return raw, c0, len(recs)
 
@@ -504,13 +517,14 @@ class UNetEngine:
                 if name not in self._w:
                     self._w[name] = (torch.zeros((2, r.rows, r.cols), dtype=torch.bfloat16, device=dev) if r.planes
                                      else torch.zeros(r.shape, dtype=torch.float32, device=dev))
-            table, chunks, n = book.device_table(self.lib, self._w, dev)
-            self._pack = (sig[1:], table, chunks, n)
-        _, table, chunks, n = self._pack
+            table, chunks, n = book.device_table(self.lib, self._w, dev, self._wf)
+            # (the fragment-major images the table does not write itself are re-made from the planes below)
+            self._pack = (sig[1:], table, chunks, n, [k for k in self._wf if k not in book or not book.frag_ok(book[k])])
+        _, table, chunks, n, wf_left = self._pack
         stream = torch.cuda.current_stream(dev).cuda_stream
         N.check(self.lib.wd_repack_multi(table.data_ptr(), n, chunks, stream), "wd_repack_multi")
-        for name, wf in self._wf.items():
-            self._pack_wf(name, wf, stream)
+        for name in wf_left:
+            self._pack_wf(name, self._wf[name], stream)
         with torch.no_grad():
             for name, meta in self._w3_meta.items():
                 self._w3[name].copy_(slab_order(self._w[name], *meta))
@@ -1050,6 +1064,7 @@ class UNetEngine:
         if wname not in self._wf:
             self._wf[wname] = torch.empty_like(self._w[wname])
             self._pack_wf(wname, self._wf[wname], torch.cuda.current_stream(self.device).cuda_stream)
+            self._pack = None  # the next refresh_weights rebuilds the repack table with this image in it
         return self._wf[wname]
 
     def _ff_fused(self, ops, p, n3, resid, M, inner, ffi, out_f32, out_pl, proj=None):
