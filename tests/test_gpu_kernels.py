@@ -425,7 +425,8 @@ def test_gemm_layernorm_of_the_result_rows(m, k, resid):
     assert lib.wd_gemm(C.byref(a), _st()) != 0  # the LDS-staged tiles (128 x 160) do not hold whole rows
 
 
-@pytest.mark.parametrize("m,inner,npass,planes", [(64, 1280, 3, True), (200, 1280, 3, False), (4096, 1280, 3, True), (130, 256, 1, True)])
+@pytest.mark.parametrize("m,inner,npass,planes", [(64, 1280, 3, True), (200, 1280, 3, False), (4096, 1280, 3, True), (130, 256, 1, True), (70, 128, 3, True),
+                                                   (64, 384, 3, False)])
 def test_fused_geglu_feed_forward(m, inner, npass, planes):
     """wd_ff_fused: x + GEGLU(LN(x) W1^T + b1) W2^T + b2 (unet.py:122-149, 343-344) in one launch - hidden activations never
     stored - vs fp64, at ragged token counts, as fp32 and as split-bf16 planes; repeated launches give the same bits."""

@@ -22,6 +22,7 @@ constexpr int FBM = 64;
 constexpr int FC = 320;          // token width (model_channels of every reference configuration that reaches this kernel)
 constexpr int FCH = 128;         // hidden units per chunk
 constexpr int FRING = 6;         // weight-fragment groups in flight per wave
+constexpr int F_MAX_INNER = 2048; // hidden width the LDS copy of b1 leaves room for (144 KB of rows and h images + 8 bytes per unit)
 constexpr int FGRP = 30;         // groups per chunk: 10 k-steps x (x, gate) + 2 k-steps x 5 column tiles
 constexpr uint32_t F_OOB = 0x80000000u;
 
@@ -39,6 +40,8 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_a = smem;
     char* s_h = smem + A_BYTES;                    // two h images
+    float* s_b1 = reinterpret_cast<float*>(smem + A_BYTES + 2 * H_BYTES);   // b1 (2 * inner floats): a global load of the bias inside
+    //                                                 the chunk loop drains the weight ring once per chunk (vmcnt counts in order)
 
     const int m0 = blockIdx.x * FBM;
     const int tid = threadIdx.x;
@@ -64,12 +67,19 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
     auto issue = [&](const int slot, const int g, const int j) {  // slot, g compile-time; j run-time (uniform)
         const bool live = j < nchunk;
         const uint32_t vo = live ? lane16 : F_OOB;
-        if (PROJ && g < FRING && !live) {
-            // the first groups of "chunk nchunk" are the first groups of the proj_out product (k-step 2 (g / 5) + kh, tile g % 5)
+        if (PROJ && g < FRING) {
+            // the first groups of "chunk nchunk" are the first groups of the proj_out product (k-step 2 (g / 5) + kh, tile g % 5): ONE
+            // pair of loads with the descriptor and offset selected - a load inside a run-time branch makes hipcc's wait-count pass
+            // assume it may not have been issued, every such branch lowers the vmcnt it dares to wait for by two, and the six of
+            // them at the end of a chunk drained the ring once per chunk
             const uint32_t so3 = (uint32_t)(((2 * (g / 5) + kh) * (FC / 16) + 5 * cg + g % 5) * 1024);
+            const uint32_t so1 = (uint32_t)(((g >> 1) * nct1 + 2 * (j * 8 + wave) + (g & 1)) * 1024);
+            const uint32_t so = live ? so1 : so3;
 #pragma unroll
-            for (int p = 0; p < NPL; ++p)
-                ring[slot][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(p ? srd3_lo : srd3_hi, lane16, so3, 0));
+            for (int p = 0; p < NPL; ++p) {
+                const __amdgpu_buffer_rsrc_t srd = live ? (p ? srd1_lo : srd1_hi) : (p ? srd3_lo : srd3_hi);
+                ring[slot][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd, lane16, so, 0));
+            }
         } else if (g < 20) {
             const uint32_t so = (uint32_t)(((g >> 1) * nct1 + 2 * (j * 8 + wave) + (g & 1)) * 1024);
 #pragma unroll
@@ -102,6 +112,7 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
         for (int sl = 0; sl < 5; ++sl)
 #pragma unroll
             for (int p = 0; p < NPL; ++p) *reinterpret_cast<f_u32x4*>(s_a + sl * SLAB + p * (FBM * 128) + dst) = v[sl][p];
+        for (int i = tid; i < 2 * a.inner; i += FNT) s_b1[i] = a.b1 ? a.b1[i] : 0.0f;
     }
     __syncthreads();
 
@@ -159,7 +170,7 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
         // ---- GEGLU on the accumulators (x and gate of an element share lane and register), h -> LDS as split-bf16 planes
         {
             const int hcol = (j * 8 + wave) * 32 + l15;            // bias index of the x unit; its gate: + 16
-            const float bx = a.b1 ? a.b1[hcol] : 0.0f, bg = a.b1 ? a.b1[hcol + 16] : 0.0f;
+            const float bx = s_b1[hcol], bg = s_b1[hcol + 16];
             const int slab = wave >> 2, ch = (wave & 3) * 2 + (l15 >> 3), e = (l15 & 7) * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -320,13 +331,15 @@ __global__ void __launch_bounds__(FNT, 1) wd_ff_kernel(const wd_ff_args a) {
 
 template <int NPASS, bool PROJ>
 int launch_ff(const wd_ff_args& a, hipStream_t st) {
-    constexpr int loop_smem = 5 * 2 * FBM * 128 + 2 * 2 * 2 * FBM * 128;  // token rows + two h images
+    constexpr int max_smem = 5 * 2 * FBM * 128 + 2 * 2 * 2 * FBM * 128 + 2 * F_MAX_INNER * 4;  // token rows + two h images + b1
     constexpr int red_smem = FBM * (FC + 4) * 4 + WD_STAT_SCRATCH;
-    constexpr int smem = loop_smem > red_smem ? loop_smem : red_smem;
+    static_assert(max_smem <= 160 * 1024 && red_smem <= max_smem, "LDS budget");
+    const int loop_smem = max_smem - 2 * (F_MAX_INNER - a.inner) * 4;
+    const int smem = loop_smem > red_smem ? loop_smem : red_smem;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wd_ff_kernel<NPASS, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                smem) != hipSuccess)
+                                max_smem) != hipSuccess)
             return WD_ELAUNCH;
         attr_done = true;
     }
@@ -341,7 +354,7 @@ int launch_ff(const wd_ff_args& a, hipStream_t st) {
 
 extern "C" int wd_ff_args_bytes(void) { return (int)sizeof(wd_ff_args); }
 
-extern "C" int wd_ff_supported(int c, int inner) { return (c == FC && inner > 0 && inner % FCH == 0) ? 1 : 0; }
+extern "C" int wd_ff_supported(int c, int inner) { return (c == FC && inner > 0 && inner % FCH == 0 && inner <= F_MAX_INNER) ? 1 : 0; }
 
 extern "C" int wd_ff_fused(const wd_ff_args* pa, void* stream) {
     if (!pa) return WD_EINVAL;
