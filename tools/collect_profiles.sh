@@ -46,5 +46,8 @@ STEPS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace 
 M=$(find $OUT/${TAG}_pmc_mfma_train -name "*counter_collection.csv" | head -1)
 python3 $ROOT/tools/pmc_mfma.py "$M" > $OUT/${TAG}_pmc_mfma_util_train.json
 rm -rf $OUT/${TAG}_pmc_mfma_train
+# shader clock / socket power under the fused feed-forward on all CUs and on eight workgroups (the power cap)
+{ echo "wd_ff_fused, m = 16384 (256 workgroups): count, sclk, socket W"; bash $ROOT/tools/clock_watch.sh 15 python3 $ROOT/tools/ff_bench.py --proj 1 --m 16384 --iters 250000;
+  echo "wd_ff_fused, m = 512 (8 workgroups)"; bash $ROOT/tools/clock_watch.sh 15 python3 $ROOT/tools/ff_bench.py --proj 1 --m 512 --iters 350000; } > $OUT/${TAG}_clock_power.txt 2>/dev/null
 echo "[collect] done"
 ls $OUT | grep "^${TAG}_"
