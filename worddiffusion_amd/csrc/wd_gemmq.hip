@@ -90,8 +90,10 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
     // one k-step: A fragments of row tile i from slab rows rb[i] + shift + (lane row), read right before its 15 MFMAs (one tile ahead)
+    // `skip`: bit i = every source row of row tile i lies above / below the image for this tap (zero rows: their 15 MFMAs add exact
+    // zeros and are left out - a sixth of a 4 x 16 map's convolution work, a third of a 2 x 32 map's)
     auto mfma_step = [&](const char* base, const int cpl, const int (&rb)[4], const int shift0, const int lm, const int half,
-                         const bf16x8 (&fb)[5][2]) {
+                         const bf16x8 (&fb)[5][2], const int skip) {
         const int ach = half * 4 + lq;
         const int shift = shift0 + lm * l15 - l15;   // (the reads below add l15)
         bf16x8 xa[2][2];
@@ -107,6 +109,7 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
                 xa[(i + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(base + ao);
                 xa[(i + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(base + cpl + ao);
             }
+            if (skip & (1 << i)) continue;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i & 1][1], fb[t][0], acc[i][t], 0, 0, 0);
@@ -138,10 +141,16 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
         const int lm = conv ? ST : 1;                    // slab rows between neighbouring output positions
         const __amdgpu_buffer_rsrc_t srd_a_hi = make_srd(q.hi), srd_a_lo = make_srd(q.lo);
         int rb[4];
+        int skm0 = 0, skm2 = 0;   // row tiles whose source rows are all outside the image for the taps of kernel row 0 / 2
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 16 * i;
             rb[i] = conv ? ST * (p >> wsh) * SW + ST * (p & (W - 1)) : p;   // tap (0, 0) of the tile's first position
+            if (conv) {
+                const int ys = ST * (y0 + (p >> wsh)) - 1;   // source row of kernel row 0 (a row tile of 16 positions lies in one row)
+                if (ys < 0) skm0 |= 1 << i;
+                if (ys + 2 >= Hs) skm2 |= 1 << i;
+            }
         }
         for (int c_lo = 0; c_lo < cpt; c_lo += pchunks) {
             const int nch = min(pchunks, cpt - c_lo);
@@ -161,6 +170,11 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
                 } else {
                     c += 4;
                 }
+            };
+            auto skip_of = [&](const int r) {   // (wave-uniform: r is)
+                if (!conv) return 0;
+                const int ky = (r >> 1) / 3;
+                return __builtin_amdgcn_readfirstlane(ky == 0 ? skm0 : ky == 2 ? skm2 : 0);
             };
             auto shift_of = [&](const int r) {
                 if (!conv) return 0;
@@ -225,13 +239,13 @@ __global__ void __launch_bounds__(QNT, 1) wd_gemmq_kernel(const wd_gemm_args a, 
                 load_b(yb, kabs_of(nc, nr), kpc * nc + nr < nks);
                 advance(nc, nr);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, xb);
+                mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, xb, skip_of(cr));
                 __builtin_amdgcn_sched_barrier(0);
                 advance(cc, cr);
                 load_b(xb, kabs_of(nc, nr), kpc * nc + nr < nks);
                 advance(nc, nr);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kpc * cc + cr < nks) mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, yb);
+                if (kpc * cc + cr < nks) mfma_step(smem + cc * chb, cpl, rb, shift_of(cr), lm, cr & 1, yb, skip_of(cr));
                 __builtin_amdgcn_sched_barrier(0);
                 advance(cc, cr);
             }

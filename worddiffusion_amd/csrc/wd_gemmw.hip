@@ -124,6 +124,18 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
         }
     }
     __syncthreads();
+    // Row tiles (16 rows) whose source rows are ALL outside the image for a tap (the top image row under kernel row 0, the bottom one
+    // under kernel row 2): their operands are exact zeros and their 15 MFMAs per k-step are left out - a twelfth of the work of a
+    // 3x3 convolution over 8 x 32 maps.  Bit 4 tap + i, from the table itself (any gather table, not only the arithmetic one).
+    unsigned long long skipmask = 0;
+    if (RH == 1 && a.src[0].gather) {
+        for (int t = 0; t < a.src[0].ntaps; ++t) {
+            const unsigned long long oob = __ballot(s_tab[t * BM + lane] < 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (((oob >> (16 * i)) & 0xFFFFull) == 0xFFFFull) skipmask |= 1ull << (4 * t + i);
+        }
+    }
 
     auto make_srd = [](const wd_bf16* p) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<wd_bf16*>(p), 0, 0x7FFFFFF0, 0x00020000);
@@ -169,9 +181,14 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
     const __amdgpu_buffer_rsrc_t srd1_hi = make_srd(p1h), srd1_lo = make_srd(p1l);
     uint32_t a_voff[RH];
     auto locate = [&]() {
+        // (the lane index is re-derived here by a volatile asm - two VALU instructions once per tap - so that no register has to hold
+        // the thread's table address across the whole loop: at 255 VGPRs hipcc spilled it and reloaded it right here, behind a
+        // vmcnt(0) that drained the weight loads in flight)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            const int row = arow + 64 * j;
+            const int row = wave * 8 + (ln >> 3) + 64 * j;   // (= arow + 64 j)
             int r;
             if (s == 0) r = s_tab[tap * BM + row];
             else r = (m0 + row < a.m) ? m0 + row : -1;  // src[1] is an identity source (1x1 skip)
@@ -289,18 +306,42 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             for (int p = 0; p < NPL; ++p) xa[i][p] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + ao);
         }
     };
-    auto mfma_all = [&](const bf16x8 (&fb)[5][NPL]) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
+    auto mfma_all = [&](const bf16x8 (&fb)[5][NPL], const int skip) {
+        if constexpr (RH == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (NPL == 2) {
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], fb[t][0], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][NPL - 1], acc[i][t], 0, 0, 0);
+                if (skip & (1 << i)) continue;   // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    if (NPL == 2) {
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], fb[t][0], acc[i][t], 0, 0, 0);
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][NPL - 1], acc[i][t], 0, 0, 0);
+                    }
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][0], acc[i][t], 0, 0, 0);
                 }
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][0], acc[i][t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (NPL == 2) {
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][NPL - 1], fb[t][0], acc[i][t], 0, 0, 0);
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][NPL - 1], acc[i][t], 0, 0, 0);
+                    }
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][0], fb[t][0], acc[i][t], 0, 0, 0);
+                }
             }
         }
+    };
+    // the all-zero row tiles of stage kit of this K slice (tap = absolute stage / chunks per tap, by multiply-shift: exact below 1024)
+    const uint32_t cpt0_inv = (65536u + (uint32_t)cpt0 - 1u) / (uint32_t)cpt0;
+    auto skip_of = [&](const int kit) {
+        if constexpr (RH != 1) return 0;
+        const int ka = k_begin + kit;
+        const int tp = (int)(((uint32_t)ka * cpt0_inv) >> 16);
+        const int sk = (ka < n0st && ka < 1024) ? (int)((skipmask >> (4 * tp)) & 15ull) : 0;
+        return __builtin_amdgcn_readfirstlane(sk);
     };
 
     // ---- prologue: A(0) into buffer 0, A(1) on its way, W(0) on its way
@@ -347,7 +388,7 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             __builtin_amdgcn_sched_barrier(0);
             WD_STAMP_LGKM();
             WD_STAMP(2);
-            mfma_all(bcur);
+            mfma_all(bcur, skip_of(kit));
             __builtin_amdgcn_sched_barrier(0);
             WD_STAMP(3);
         };
@@ -364,7 +405,7 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             WD_STAMP(1);
             const char* base = smem + (kit & 1) * STAGE;
             char* nbase = smem + ((kit + 1) & 1) * STAGE;
-            if (kit > 0) mfma_all(bset);     // stage kit - 1, fragments read before the barrier
+            if (kit > 0) mfma_all(bset, skip_of(kit - 1));     // stage kit - 1, fragments read before the barrier
             __builtin_amdgcn_sched_barrier(0);
             WD_STAMP(2);                     // (late group: [1..2] = MFMA, [2..3] = memory phase)
             store_a(nbase);
@@ -381,7 +422,7 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
             late_step(kit, yb);
             late_step(kit + 1, xb);
         }
-        if (nk > 0) mfma_all(yb);  // the last (possibly phantom) stage: index odd, set yb
+        if (nk > 0) mfma_all(yb, skip_of(((nk + 1) & ~1) - 1));  // the last (possibly phantom) stage: index odd, set yb
     }
 #undef WD_STAMP
 #undef WD_STAMP_LGKM
