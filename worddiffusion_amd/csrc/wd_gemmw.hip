@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
         if constexpr (RH != 1) return 0;
         const int ka = k_begin + kit;
         const int tp = (int)(((uint32_t)ka * cpt0_inv) >> 16);
-        const int sk = (ka < n0st && ka < 1024) ? (int)((skipmask >> (4 * tp)) & 15ull) : 0;
+        int sk = (ka < n0st && ka < 1024) ? (int)((skipmask >> (4 * tp)) & 15ull) : 0;
+        if (kit >= nk) sk = 15;   // the phantom stage of an odd stage count: all-zero operands
         return __builtin_amdgcn_readfirstlane(sk);
     };
 
