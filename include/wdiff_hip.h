@@ -147,6 +147,14 @@ typedef struct wd_gemm_args {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_eps;
+    /* Weight groups (w_layout 3, tile 64320, no K cut): w_ngroups > 1 cuts the hw_out rows of every sample into w_ngroups equal
+     * runs (each a multiple of 64 rows); run g multiplies with the fragment-major image at w_hi / w_lo + g * w_group_stride
+     * elements.  The nearest x2 upsample + 3x3 convolution (Upsample.forward, unet.py:488-499) runs this way as its four output
+     * phases (row parity, column parity): a phase reads a 2 x 2 neighbourhood of the SOURCE map with the kernel taps that fall
+     * on the same source pixel summed - 4 taps instead of 9; the rows of a sample come out phase-major (wd_gn_apply2's perm_a
+     * reads them back in raster order). */
+    int32_t w_ngroups;
+    int64_t w_group_stride;
 } wd_gemm_args;
 
 int wd_gemm(const wd_gemm_args* args, void* stream);
@@ -236,7 +244,7 @@ int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int cpg, const
 int wd_gn_apply2(const float* xa, int lda, int ca, const double* part_a, int nchunk_a, int part_cpg_a, int c_off_a,
                  const float* xb, int ldb, int cb, const double* part_b, int nchunk_b, int part_cpg_b, int c_off_b,
                  int batch, int hw, int cpg, const float* gamma, const float* beta, float eps, int silu,
-                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream);
+                 wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, const int32_t* perm_a, void* stream);
 
 /* out[b][o][y][x] (NCHW, o < oc <= 4) = Conv3x3(SiLU?(GroupNorm(x)))[o] + bias[o] in one launch, fp32 VALU: the UNet's last layer
  * (GroupNorm32, SiLU, conv 320 -> 4; unet.py:1453-1458) and any other few-output-channel 3x3 (pad 1, stride 1).

@@ -98,6 +98,7 @@ def test_two_source_groupnorm_in_one_launch_equals_two_launches(golden_dir):
     for fuse in (True, False):
         m = build(FULL, "base", False, golden_state_dict(g))
         m.engine.fuse_gn2 = fuse
+        m.engine.use_up_phases = False  # (the phase form of the Upsample needs the two-source launch: keep both runs on the 3x3 form)
         outs.append(call(m, "base", torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]),
                          torch.from_numpy(g["y"])))
         P = next(iter(m.engine._plans.values()))
@@ -249,6 +250,21 @@ def test_full_size_properties_b64():
     with torch.no_grad():
         ref = orc(inp["x"][:2], inp["t"][:2], inp["context"][:2], inp["y"][:2])
     assert max_rel(o1[:2].cpu(), ref) < 1e-4
+
+
+def test_upsample_as_four_phases_equals_the_nine_tap_form():
+    """Upsample (nearest x2 + conv3x3, unet.py:488-499) at the benchmark batch: four 2x2 convolutions of the source map with summed
+    taps, phase-major rows read back by the decoder block's GroupNorm (engine.use_up_phases, default) vs the 9-tap gather form -
+    the same sums in a different association."""
+    inp = synthetic_inputs(64, seed=3)
+    outs = []
+    for phases in (True, False):
+        m = build(FULL, "base", False, seed=1)
+        m.engine.use_up_phases = phases
+        outs.append(call(m, "base", inp["x"], inp["t"], inp["context"], inp["y"]))
+        P = next(iter(m.engine._plans.values()))
+        assert sum(1 for _, _, what in P.step if "4 phases" in what) == (1 if phases else 0)
+    assert torch.isfinite(outs[0]).all() and max_rel(outs[0].cpu(), outs[1].cpu()) < 2e-5
 
 
 def test_full_size_properties_b64_phosc():

@@ -70,6 +70,30 @@ def test_gather_tables_equal_torch_convs(h, w):
     assert torch.allclose(_gather_conv(x, wt, b, "up"), up, atol=1e-5)
 
 
+@pytest.mark.parametrize("h,w", [(4, 16), (2, 8), (3, 5)])
+def test_upsample_as_four_phase_convolutions(h, w):
+    """upsample_phase_tables / upsample_phase_weights (four 2x2 convolutions of the source map, rows phase-major, read back through
+    the raster permutation) == F.interpolate(nearest x2) + conv3x3 pad 1 (Upsample.forward, unet.py:488-499)."""
+    from worddiffusion_amd.engine import upsample_phase_tables, upsample_phase_weights
+    g = torch.Generator().manual_seed(h * 10 + w)
+    x = torch.randn(2, 6, h, w, generator=g)
+    wt = torch.randn(5, 6, 3, 3, generator=g)
+    b = torch.randn(5, generator=g)
+    tab, perm = upsample_phase_tables(h, w)
+    wph = upsample_phase_weights(wt)                      # [phase][tap][n][c]
+    hw = h * w
+    tok = torch.cat([x.permute(0, 2, 3, 1).reshape(2, hw, 6), torch.zeros(2, 1, 6)], 1)   # index -1 -> zero row
+    a = torch.cat([tok[:, torch.from_numpy(tab[t]).long()] for t in range(4)], dim=2)     # [B, 4 hw, 4 C], rows phase-major
+    out = torch.empty(2, 4 * hw, 5)
+    for ph in range(4):
+        wp = wph[ph].permute(1, 0, 2).reshape(5, 4 * 6)    # [n][tap * C + c]
+        out[:, ph * hw:(ph + 1) * hw] = a[:, ph * hw:(ph + 1) * hw] @ wp.t() + b
+    raster = out[:, torch.from_numpy(perm).long()].reshape(2, 2 * h, 2 * w, 5).permute(0, 3, 1, 2)
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    assert torch.allclose(raster, want, atol=1e-5)
+    assert sorted(perm.tolist()) == list(range(4 * hw))
+
+
 def test_geglu_interleave_pairs_columns():
     w = torch.arange(2 * 64 * 3, dtype=torch.float32).reshape(128, 3)
     p = geglu_interleave(w, 32)

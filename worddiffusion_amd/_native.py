@@ -41,7 +41,8 @@ class WdGemmArgs(C.Structure):
                 ("tickets", _vp), ("ntickets", C.c_int32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_eps", C.c_float),
                 ("gn_silu", C.c_int32), ("gn_cpg", C.c_int32), ("a32", _vp), ("a32_ld", C.c_int32), ("a32_part", _vp),
                 ("a32_nchunk", C.c_int32), ("a32_pcpg", C.c_int32), ("a32_cpg", C.c_int32), ("a32_gamma", _vp), ("a32_beta", _vp),
-                ("a32_eps", C.c_float), ("a32_silu", C.c_int32), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", C.c_float)]
+                ("a32_eps", C.c_float), ("a32_silu", C.c_int32), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", C.c_float),
+                ("w_ngroups", C.c_int32), ("w_group_stride", C.c_int64)]
 
 
 class WdFfArgs(C.Structure):
@@ -88,7 +89,7 @@ _SIGS = {
     "wd_gn_conv3x3_few": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "wd_gn_apply": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "wd_gn_apply2": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp,
-                          _vp, _vp]),
+                          _vp, _vp, _vp]),
     "wd_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wd_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "wd_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),

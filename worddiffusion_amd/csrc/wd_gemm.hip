@@ -2241,6 +2241,12 @@ extern "C" int wd_gemm(const wd_gemm_args* pa, void* stream) {
         if (a.n % (a.tile % 1000)) return WD_EINVAL;
         if (a.tile == 64080) a.ksplit = 1;  // (all of K inside the workgroup: wd_gemmq_kernel; wd_gemmq_applies() is checked at the dispatch)
     }
+    if (a.w_ngroups > 1) {
+        // weight groups: the 64 x 320 weights-to-registers kernel only, a tile inside one run of rows, no K cut
+        if (a.w_layout != 3 || a.tile != 64320 || a.ksplit > 1 || a.hw_out % (64 * a.w_ngroups) || a.w_group_stride <= 0 || (a.w_group_stride & 7))
+            return WD_EINVAL;
+        a.ksplit = 1;
+    }
     if (a.stat_part) {
         // fused GroupNorm statistics need row panels that tile the samples and whole groups inside a column tile
         if (a.stat_cpg <= 0 || a.n % a.stat_cpg || a.act == WD_ACT_GEGLU) return WD_EINVAL;

@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(WNT, 1) wd_gemmw_kernel(const wd_gemm_args a, 
     };
     // ---- weights: fragment-major, this wave's five column tiles of a k-step are 5 KB in a row
     const int nct = a.n >> 4;
-    const __amdgpu_buffer_rsrc_t srd_w_hi = make_srd(a.w_hi), srd_w_lo = make_srd(a.w_lo ? a.w_lo : a.w_hi);
+    // (weight groups, wd_gemm_args::w_ngroups: the run of rows this tile lies in picks the image)
+    const long wgrp = a.w_ngroups > 1 ? (long)((m0 % a.hw_out) / (a.hw_out / a.w_ngroups)) * a.w_group_stride : 0;
+    const __amdgpu_buffer_rsrc_t srd_w_hi = make_srd(a.w_hi + wgrp), srd_w_lo = make_srd((a.w_lo ? a.w_lo : a.w_hi) + wgrp);
     const uint32_t b_voff = (uint32_t)(((n0 >> 4) + 5 * cg) * 1024 + lane * 16);
     const uint32_t kstep_bytes = (uint32_t)nct * 1024u;
 

@@ -50,6 +50,7 @@ struct GnSrc {  // one source tensor of a GroupNorm over a channel concat: its r
     const float* x;
     const double* part;
     int ld, c, nchunk, part_cpg, c_off;
+    const int32_t* perm;  // NULL, or [hw]: the row (inside its sample) that holds position t - a producer that wrote its rows in another order
 };
 
 // grid (token tiles, batch, sources): blockIdx.z picks the source
@@ -100,7 +101,8 @@ __global__ void gn_apply_kernel(const GnSrc s0, const GnSrc s1, int hw, int cpg,
         }
         for (int t = tl; t < nt; t += rpp) {
             const long row = (long)b * hw + t0 + t;
-            const float4 v = *reinterpret_cast<const float4*>(x + row * ld + cx);
+            const long srow = sr.perm ? (long)b * hw + sr.perm[t0 + t] : row;
+            const float4 v = *reinterpret_cast<const float4*>(x + srow * ld + cx);
             float4 y = make_float4(v.x * sc[0] + sh[0], v.y * sc[1] + sh[1], v.z * sc[2] + sh[2], v.w * sc[3] + sh[3]);
             if (silu) {
                 y.x = wd_silu(y.x); y.y = wd_silu(y.y); y.z = wd_silu(y.z); y.w = wd_silu(y.w);
@@ -122,7 +124,8 @@ __global__ void gn_apply_kernel(const GnSrc s0, const GnSrc s1, int hw, int cpg,
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int t = i / c4, cx = (i - t * c4) * 4;
         const long row = (long)b * hw + t0 + t;
-        const float4 v = *reinterpret_cast<const float4*>(x + row * ld + cx);
+        const long srow = sr.perm ? (long)b * hw + sr.perm[t0 + t] : row;
+        const float4 v = *reinterpret_cast<const float4*>(x + srow * ld + cx);
         float4 y;
         {
             const int g = cx / cpg, g1 = (cx + 1) / cpg, g2 = (cx + 2) / cpg, g3 = (cx + 3) / cpg;
@@ -406,7 +409,7 @@ extern "C" int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int
     if (c % 4 || ld % 4 || out_ld % 4 || c_off % 4 || c % cpg || c / cpg > 32 || cpg % part_cpg) return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_GNAPPLY, st);
-    const GnSrc s0 = {x, part, ld, c, nchunk, part_cpg, c_off};
+    const GnSrc s0 = {x, part, ld, c, nchunk, part_cpg, c_off, nullptr};
     hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch, 1), dim3(256), 0, st, s0, s0, hw, cpg, gamma, beta, eps,
                        silu, out_hi, out_lo, out_ld, raw_hi, raw_lo);
     return wd_check_launch();
@@ -415,7 +418,8 @@ extern "C" int wd_gn_apply(const float* x, int ld, int batch, int hw, int c, int
 extern "C" int wd_gn_apply2(const float* xa, int lda, int ca, const double* part_a, int nchunk_a, int part_cpg_a, int c_off_a,
                             const float* xb, int ldb, int cb, const double* part_b, int nchunk_b, int part_cpg_b, int c_off_b,
                             int batch, int hw, int cpg, const float* gamma, const float* beta, float eps, int silu,
-                            wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, void* stream) {
+                            wd_bf16* out_hi, wd_bf16* out_lo, int out_ld, wd_bf16* raw_hi, wd_bf16* raw_lo, const int32_t* perm_a,
+                            void* stream) {
     if (!xa || !xb || !part_a || !part_b || !gamma || !beta || !out_hi || batch <= 0 || hw <= 0 || nchunk_a <= 0 || nchunk_b <= 0 ||
         part_cpg_a <= 0 || part_cpg_b <= 0)
         return WD_EINVAL;
@@ -424,7 +428,7 @@ extern "C" int wd_gn_apply2(const float* xa, int lda, int ca, const double* part
         return WD_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     WdLaunchScope scope(WD_CLS_GNAPPLY, st);
-    const GnSrc s0 = {xa, part_a, lda, ca, nchunk_a, part_cpg_a, c_off_a}, s1 = {xb, part_b, ldb, cb, nchunk_b, part_cpg_b, c_off_b};
+    const GnSrc s0 = {xa, part_a, lda, ca, nchunk_a, part_cpg_a, c_off_a, perm_a}, s1 = {xb, part_b, ldb, cb, nchunk_b, part_cpg_b, c_off_b, nullptr};
     hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + AP_TOK - 1) / AP_TOK, batch, 2), dim3(256), 0, st, s0, s1, hw, cpg, gamma, beta, eps,
                        silu, out_hi, out_lo, out_ld, raw_hi, raw_lo);
     return wd_check_launch();

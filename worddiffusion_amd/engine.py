@@ -61,6 +61,39 @@ def conv_gather_table(h: int, w: int, mode: str) -> Tuple[np.ndarray, int, int]:
     return tab, ho, wo
 
 
+def upsample_phase_tables(h: int, w: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Nearest x2 upsample + 3x3 / pad 1 convolution (Upsample.forward, unet.py:488-499) as four 2x2 convolutions of the SOURCE map,
+    one per output phase (py, px) = (row parity, column parity): the taps of the 3x3 kernel that fall on the same source pixel are
+    summed (``upsample_phase_weights``), 4 taps instead of 9.  Output rows of a sample are phase-major: q = (2 py + px) * h*w + y*w + x
+    is output pixel (2y + py, 2x + px).
+
+    Returns (int32 [4 taps][4*h*w] source position or -1, tap = 2 dy + dx reads source (y + dy - 1 + py, x + dx - 1 + px);
+             int32 [4*h*w]: the row q that holds raster position (Y, X) of the 2h x 2w map)."""
+    hw = h * w
+    tab = np.full((4, 4 * hw), -1, dtype=np.int32)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    for py in range(2):
+        for px in range(2):
+            ph = 2 * py + px
+            for dy in range(2):
+                for dx in range(2):
+                    sy, sx = yy + dy - 1 + py, xx + dx - 1 + px
+                    ok = (sy >= 0) & (sy < h) & (sx >= 0) & (sx < w)
+                    tab[2 * dy + dx, ph * hw:(ph + 1) * hw] = np.where(ok, sy * w + sx, -1).reshape(-1)
+    Y, X = np.meshgrid(np.arange(2 * h), np.arange(2 * w), indexing="ij")
+    perm = ((2 * (Y % 2) + (X % 2)) * hw + (Y // 2) * w + (X // 2)).reshape(-1).astype(np.int32)
+    return tab, perm
+
+
+def upsample_phase_weights(w: torch.Tensor) -> torch.Tensor:
+    """[N, C, 3, 3] -> [4 phases][4 taps][N][C] fp32: kernel rows {0} / {1, 2} feed source rows y - 1 / y of an even output row,
+    {0, 1} / {2} feed y / y + 1 of an odd one (the same for columns); phase = 2 py + px, tap = 2 dy + dx."""
+    sel = torch.tensor([[[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]]], dtype=torch.float32, device=w.device)  # [parity][d][k]
+    out = torch.einsum("pdk,qel,nckl->pqdenc", sel, sel, w.detach().float())
+    n, c = w.shape[0], w.shape[1]
+    return out.reshape(4, 4, n, c).contiguous()
+
+
 def geglu_interleave(w: torch.Tensor, g: int = 32) -> torch.Tensor:
     """Rows [x | gate] (unet.py:128 ``chunk(2)``) -> blocks of ``g`` x-rows followed by their ``g`` gate rows, so
     that one BN = 2g column tile of ``wd_gemm`` holds both halves of ``g`` output columns."""
@@ -254,10 +287,12 @@ class RecipeBook(dict):
 
 class Act:
     """A token-major fp32 feature map [B*h*w, c] on the device."""
-    __slots__ = ("t", "c", "h", "w", "stats", "prod")
+    __slots__ = ("t", "c", "h", "w", "stats", "prod", "perm")
 
-    def __init__(self, t, c, h, w, stats=None, prod=None):
+    def __init__(self, t, c, h, w, stats=None, prod=None, perm=None):
         self.t, self.c, self.h, self.w = t, c, h, w
+        self.perm = perm    # None, or int32 [h*w] on the device: the row (inside its sample) that holds raster position p - the
+        #                     phase-major output of an Upsample (only the two-source GroupNorm of a decoder block reads such a map)
         self.stats = stats  # (part tensor [B, nchunk, c / part_cpg, 2] f64, nchunk, part_cpg) once known
         self.prod = prod    # the WdGemmArgs of the GEMM whose epilogue writes ``t``: a consumer that wants the operand planes of
         #                     this very tensor asks that epilogue for them instead of launching wd_split
@@ -316,6 +351,9 @@ class UNetEngine:
         # 64 x 320 tiles with the weights loaded straight into the MFMA operand registers (csrc/wd_gemmw.hip): the 320-column
         # layers whose grid fills the chip without a K cut
         self.use_wdirect = os.environ.get("WDIFF_GEMM_WDIRECT", "1") != "0"
+        # Upsample as four 2x2 convolutions of the source map (one per output phase, 4 taps instead of 9; upsample_phase_tables)
+        self.use_up_phases = os.environ.get("WDIFF_UPSAMPLE_PHASES", "1") != "0"
+        self._derived: Dict[str, tuple] = {}   # name -> (persistent fp32 tensor, function that recomputes it from the parameters)
         self.use_smallmap = os.environ.get("WDIFF_GEMM_SMALLMAP", "1") != "0"  # 64 x 80 whole-K tiles for 3x3 layers over 64-position samples
         # GEGLU feed-forward + residual in one launch per 64-token panel, hidden activations on chip (csrc/wd_ff.hip)
         self.fuse_ff = os.environ.get("WDIFF_FUSE_FF", "1") != "0"
@@ -403,6 +441,17 @@ class UNetEngine:
                 conv = mod.op if isinstance(mod, DownsampleParams) else mod.conv
                 R.matrix(name + ".w", mod.cout, 9 * mod.cin).fwd(conv.weight)
                 R.vector(name + ".b", conv.bias)
+                if isinstance(mod, UpsampleParams) and self._up_phases_ok(mod):
+                    # the four phase matrices [cout][4 taps x cin] from a derived tensor (the summed taps), refreshed before every repack
+                    key = name + ".wph"
+                    if key not in self._derived or self._derived[key][0].device != conv.weight.device:
+                        self._derived[key] = (torch.empty((4, 4, mod.cout, mod.cin), dtype=torch.float32, device=conv.weight.device),
+                                              (lambda cv=conv: upsample_phase_weights(cv.weight)))
+                    wph = self._derived[key][0]
+                    for ph in range(4):
+                        r = R.matrix(f"{name}.wph{ph}", mod.cout, 4 * mod.cin)
+                        for t in range(4):
+                            r.fwd(wph[ph, t], col_off=t * mod.cin)
             elif isinstance(mod, SpatialTransformerParams):
                 inner = mod.heads * mod.d_head
                 R.vector(name + ".gn.g", mod.norm.weight)
@@ -522,6 +571,9 @@ class UNetEngine:
             self._pack = (sig[1:], table, chunks, n, [k for k in self._wf if k not in book or not book.frag_ok(book[k])])
         _, table, chunks, n, wf_left = self._pack
         stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.no_grad():
+            for buf, fn in self._derived.values():
+                buf.copy_(fn())
         N.check(self.lib.wd_repack_multi(table.data_ptr(), n, chunks, stream), "wd_repack_multi")
         for name in wf_left:
             self._pack_wf(name, self._wf[name], stream)
@@ -703,6 +755,9 @@ class UNetEngine:
         hw = h * w
         ctot = sum(s.c for s in srcs)
         cpg = ctot // 32
+        has_perm = any(s.perm is not None for s in srcs)
+        if has_perm and not (len(srcs) == 2 and srcs[1].perm is None and self.fuse_gn2 and not any(s.c % cpg for s in srcs)):
+            raise NotImplementedError(f"{what}: a phase-major map (Upsample) is read by the two-source GroupNorm of a decoder block only")
         if any(s.c % cpg for s in srcs):
             # groups straddle the concat boundary: materialise the concat (never the case at 320+320 channels)
             cat = self._f32(P, B * hw, ctot)
@@ -737,7 +792,7 @@ class UNetEngine:
                 ops.append((self.lib.wd_gn_fold_chunks, (part.data_ptr(), B, nchunk, ngs, folded.data_ptr()), what + ":fold chunks"))
                 part, nchunk = folded, 1
                 s.stats = (part, nchunk, pc)
-            if self._gn_in_combine(s, raw, hw, cpg, pc, nchunk, coff):
+            if not has_perm and self._gn_in_combine(s, raw, hw, cpg, pc, nchunk, coff):
                 # the producer is a K-cut GEMM whose combine tiles (64 rows x 40 columns) hold whole (sample, group) blocks: its
                 # combine launch normalises the rows it has just summed and writes these planes (wd_gemm_args.gn_*)
                 pr = s.prod
@@ -756,9 +811,11 @@ class UNetEngine:
             (sa, pa, na, pca, ca), (sb, pb, nb_, pcb, cb) = todo
             ops.append((self.lib.wd_gn_apply2,
                         (sa.t.data_ptr(), sa.c, sa.c, pa.data_ptr(), na, pca, ca, sb.t.data_ptr(), sb.c, sb.c, pb.data_ptr(), nb_, pcb, cb,
-                         B, hw, cpg, gam.data_ptr(), bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), lo, ctot, rhi, rlo),
+                         B, hw, cpg, gam.data_ptr(), bet.data_ptr(), eps, int(silu), pl[0].data_ptr(), lo, ctot, rhi, rlo,
+                         sa.perm.data_ptr() if sa.perm is not None else None),
                         what + ":apply"))
         else:
+            assert not has_perm, what
             for s, part, nchunk, pc, c0 in todo:
                 ops.append((self.lib.wd_gn_apply,
                             (s.t.data_ptr(), s.c, B, hw, s.c, cpg, part.data_ptr(), nchunk, pc, gam.data_ptr(), bet.data_ptr(), eps,
@@ -864,9 +921,15 @@ class UNetEngine:
                             out_ld=cout, want_stats=True, a32=in2)
         return Act(out, cout, h, w, g2._stats, prod=g2)
 
+    def _up_phases_ok(self, mod) -> bool:
+        """Shapes the phase form of an Upsample covers (the 64 x 320 weights-to-registers kernel with weight groups)."""
+        return (getattr(self, "use_up_phases", False) and self.use_wdirect and self.fuse_gn2 and self.npass == 3 and not self.use_slab and
+                not self.use_conv3 and mod.cin % 64 == 0 and mod.cout % 320 == 0)
+
     def _resample(self, P, name, mod, x: Act, mode: str, tile: int = 0) -> Act:
         ops = P.step
         B = self._B
+        assert x.perm is None, name
         tab, ho, wo = self._table(x.h, x.w, mode)
         pl = self._planes(P, B * x.h * x.w, x.c)
         pr = x.prod
@@ -879,6 +942,30 @@ class UNetEngine:
             ops.append((self.lib.wd_split, (x.t.data_ptr(), x.c, B * x.h * x.w, x.c, 0, pl[0].data_ptr(),
                                             pl[1].data_ptr() if self.npass == 3 else None, x.c), name + ":split"))
         out = self._f32(P, B * ho * wo, mod.cout)
+        hw = x.h * x.w
+        if (mode == "up" and tile == 0 and (name + ".wph0") in self._w and self._up_phases_ok(mod) and hw % 64 == 0 and
+                (B * 4 * hw // 64) * (mod.cout // 320) >= 256):
+            # four 2x2 convolutions of the source map, one per output phase: 4 taps instead of 9, the weight image picked per tile;
+            # the rows of a sample come out phase-major (Act.perm: the decoder block's GroupNorm reads them in raster order)
+            key = (x.h, x.w, "up4")
+            if key not in self._tabs:
+                t4, pm = upsample_phase_tables(x.h, x.w)
+                dt, dp = torch.from_numpy(t4).to(self.device), torch.from_numpy(pm).to(self.device)
+                self._tabs[key] = (dt, dp)
+                self._tab_np[dt.data_ptr()] = t4
+            tab4, perm = self._tabs[key]
+            if (name + ".wph0") not in self._wf:   # the four fragment-major images side by side (one base + a stride for the kernel)
+                grp = torch.empty((2, 4, mod.cout, 4 * x.c), dtype=torch.bfloat16, device=self.device)
+                st = torch.cuda.current_stream(self.device).cuda_stream
+                for ph in range(4):
+                    self._wf[f"{name}.wph{ph}"] = grp[:, ph]
+                    self._pack_wf(f"{name}.wph{ph}", grp[:, ph], st)
+                self._pack = None
+            gg = self._gemm(ops, name + ".conv (4 phases)", [self._src(pl, x.c, 4, tab4, hw)], name + ".wph0", B * 4 * hw, 4 * hw,
+                            bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True)
+            assert gg.tile == 64320 and gg.w_layout == 3, name
+            gg.w_ngroups, gg.w_group_stride = 4, mod.cout * 4 * x.c
+            return Act(out, mod.cout, ho, wo, gg._stats, prod=None, perm=perm)
         gg = self._gemm(ops, name + ".conv", [self._src(pl, x.c, 9, tab, x.h * x.w)], name + ".w", B * ho * wo, ho * wo,
                         bias=self._w[name + ".b"], out_f32=out, out_ld=mod.cout, want_stats=True, tile=tile)
         return Act(out, mod.cout, ho, wo, gg._stats, prod=gg)

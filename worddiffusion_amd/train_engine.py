@@ -64,6 +64,7 @@ class TrainEngine(UNetEngine):
         # (the fragment-major weight images of the whole-K kernel have to be rebuilt after every optimiser step: wd_gemm_pack_w launches)
         self.use_smallmap = os.environ.get("WDIFF_TRAIN_SMALLMAP", "1") != "0"   # (forward only; measured -0.085 ms per step with the pack launches)
         self.fuse_ff = self.fuse_proj = False
+        self.use_up_phases = False   # (the backward pass differentiates the 3x3 form)
         self.fuse_gn_in = 0
         self.use_dw = os.environ.get("WDIFF_TRAIN_DW", "1") != "0"  # weight gradients through wd_dw (csrc/wd_dw.hip) where it applies
         self.fuse_geglu_bwd = os.environ.get("WDIFF_FUSE_GEGLU_BWD", "1") != "0"  # GEGLU backward inside the d(out) preparation of ff1
