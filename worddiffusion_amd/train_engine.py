@@ -57,12 +57,11 @@ def _rup(x: int, m: int) -> int:
 class TrainEngine(UNetEngine):
     def __init__(self, model, variant: str):
         super().__init__(model, variant)
-        # the weights-to-registers GEMM needs a fragment-major image of every weight it reads, rebuilt after each optimiser step
-        # (34 wd_gemm_pack_w launches, 0.16 ms) - and measured no faster on the training forward: 14.62 vs 14.43 ms per step.
+        # the weights-to-registers GEMM is no faster on the training forward (11.03-11.14 ms per step without it, 11.18-11.25 with it at the
+        # end of round 3 - its fragment-major weight images now come out of the repack launch itself, so that is the kernels alone).
         # The fused feed-forward does not keep the hidden activations the backward pass needs.
         self.use_wdirect = os.environ.get("WDIFF_TRAIN_WDIRECT", "0") != "0"
-        # (the fragment-major weight images of the whole-K kernel have to be rebuilt after every optimiser step: wd_gemm_pack_w launches)
-        self.use_smallmap = os.environ.get("WDIFF_TRAIN_SMALLMAP", "1") != "0"   # (forward only; measured -0.085 ms per step with the pack launches)
+        self.use_smallmap = os.environ.get("WDIFF_TRAIN_SMALLMAP", "1") != "0"   # (forward only; -0.085 ms per step)
         self.fuse_ff = self.fuse_proj = False
         self.use_up_phases = False   # (the backward pass differentiates the 3x3 form)
         self.fuse_gn_in = 0
