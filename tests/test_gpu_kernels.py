@@ -589,6 +589,79 @@ def test_gemm_two_workgroups_per_cu_kernel_geglu():
         assert rel_err(out.cpu(), ref) < tol and rel_err(unplanes(pl).cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("B,h,w,cin,cout", [(4, 4, 16, 64, 320), (2, 8, 8, 128, 320)])
+def test_gemm_weight_groups_upsample_as_four_phases(B, h, w, cin, cout):
+    """wd_gemm_args.w_ngroups: nearest x2 + conv3x3 (Upsample.forward, unet.py:488-499) as four 2x2 convolutions of the source map in
+    one launch - a tile picks the weight image of its output phase - and wd_gn_apply2's perm_a reading the phase-major rows back in
+    raster order; against F.interpolate + F.conv2d in fp64.  Bad combinations are rejected."""
+    from worddiffusion_amd.engine import upsample_phase_tables, upsample_phase_weights
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B * 100 + cin)
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), bias.double(), padding=1)
+    ref_tok = ref.permute(0, 2, 3, 1).reshape(B * 4 * h * w, cout)          # raster rows
+    hw = h * w
+    tab, perm = upsample_phase_tables(h, w)
+    wph = upsample_phase_weights(wt)                                         # [phase][tap][n][c]
+    tok = planes_of(x.permute(0, 2, 3, 1).reshape(B * hw, cin).to(DEV))
+    imgs = torch.empty(2, 4, cout, 4 * cin, dtype=torch.bfloat16, device=DEV)
+    for ph in range(4):
+        wp = planes_of(wph[ph].permute(1, 0, 2).reshape(cout, 4 * cin).contiguous().to(DEV))
+        N.check(lib.wd_gemm_pack_w(wp[0].data_ptr(), wp[1].data_ptr(), cout, 4 * cin, imgs[0, ph].data_ptr(), imgs[1, ph].data_ptr(),
+                                   _st()), "wd_gemm_pack_w")
+    tabd, permd, bd = torch.from_numpy(tab).to(DEV), torch.from_numpy(perm).to(DEV), bias.to(DEV)
+    m = B * 4 * hw
+    out = torch.full((m, cout), float("nan"), device=DEV)
+    part = torch.zeros(B, 4 * hw // 64, 32, 2, dtype=torch.float64, device=DEV)
+    a = N.WdGemmArgs()
+    s0 = N.WdSrc()
+    s0.hi, s0.lo, s0.gather = tok[0].data_ptr(), tok[1].data_ptr(), tabd.data_ptr()
+    s0.ld, s0.c, s0.ntaps, s0.hw_src = cin, cin, 4, hw
+    a.src[0] = s0
+    a.nsrc, a.npass = 1, 3
+    a.w_hi, a.w_lo = imgs[0].data_ptr(), imgs[1].data_ptr()
+    a.w_layout, a.tile, a.ksplit = 3, 64320, 1
+    a.w_ngroups, a.w_group_stride = 4, cout * 4 * cin
+    a.m, a.n, a.ktot, a.hw_out = m, cout, 4 * cin, 4 * hw
+    a.bias = bd.data_ptr()
+    a.out_f32, a.out_ld = out.data_ptr(), cout
+    a.stat_part, a.stat_cpg = part.data_ptr(), cout // 32
+    N.check(lib.wd_gemm(C.byref(a), _st()), "wd_gemm (weight groups)")
+    torch.cuda.synchronize()
+    raster = out.reshape(B, 4 * hw, cout)[:, permd.long()].reshape(m, cout)
+    assert rel_err(raster.cpu(), ref_tok) < 2e-5
+    # the statistics of the phase-major map are those of the raster map (sums over a sample)
+    sums = part.sum(1).cpu()                                                  # [B][32][2]
+    grp = ref_tok.reshape(B, 4 * hw, 32, cout // 32)
+    assert torch.allclose(sums[..., 0], grp.sum((1, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(sums[..., 1], (grp * grp).sum((1, 3)), rtol=1e-4, atol=1e-3)
+    # GroupNorm over [this map | a raster-ordered second source] reads the first through the permutation
+    skip = torch.randn(m, cout, generator=g)
+    gam, bet = torch.randn(2 * cout, generator=g), torch.randn(2 * cout, generator=g)
+    cat = torch.cat([ref_tok, skip.double()], 1).reshape(B, 4 * hw, 2 * cout).permute(0, 2, 1)
+    gref = F.silu(F.group_norm(cat, 32, gam.double(), bet.double(), 1e-5)).permute(0, 2, 1).reshape(m, 2 * cout)
+    skd = skip.to(DEV)
+    nchunk = lib.wd_gn_nchunk(4 * hw)
+    part_b = torch.zeros(B, nchunk, 32, 2, dtype=torch.float64, device=DEV)
+    N.check(lib.wd_gn_stats(skd.data_ptr(), cout, B, 4 * hw, cout, cout // 32, part_b.data_ptr(), _st()), "stats")
+    pl, raw = torch.zeros(2, m, 2 * cout, dtype=torch.bfloat16, device=DEV), torch.zeros(2, m, 2 * cout, dtype=torch.bfloat16, device=DEV)
+    gd, btd = gam.to(DEV), bet.to(DEV)
+    N.check(lib.wd_gn_apply2(out.data_ptr(), cout, cout, part.data_ptr(), 4 * hw // 64, cout // 32, 0,
+                             skd.data_ptr(), cout, cout, part_b.data_ptr(), nchunk, cout // 32, cout,
+                             B, 4 * hw, 2 * cout // 32, gd.data_ptr(), btd.data_ptr(), 1e-5, 1, pl[0].data_ptr(), pl[1].data_ptr(), 2 * cout,
+                             raw[0].data_ptr(), raw[1].data_ptr(), permd.data_ptr(), _st()), "wd_gn_apply2 (perm)")
+    torch.cuda.synchronize()
+    assert max_rel(unplanes(pl).cpu(), gref) < 5e-5
+    assert max_rel(unplanes(raw).cpu()[:, :cout], ref_tok) < 3e-5
+    # rejected: another tile, a K cut, runs that are not whole 64-row tiles
+    for field, val in (("tile", 128160), ("ksplit", 2), ("w_ngroups", 3), ("w_group_stride", 0)):
+        b = N.WdGemmArgs.from_buffer_copy(a)
+        setattr(b, field, val)
+        assert lib.wd_gemm(C.byref(b), _st()) == N.WD_EINVAL, field
+
+
 def test_gemm_rejects_bad_arguments():
     lib = N.lib()
     a = N.WdGemmArgs()
